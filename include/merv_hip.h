@@ -1,0 +1,162 @@
+/*
+ * merv_hip.h -- C ABI of libmerv_hip.so: the MI355X (gfx950) implementation of MERV's multi-encoder video
+ * forward path (four visual encoders -> 3davg+linear projectors -> cross-encoder fusion -> BOS splice),
+ * plus the bit-exact frame-index sampler.
+ *
+ * The reference (princetonvisualai/merv) is pure Python; there is no FFI in it. Each entry point below
+ * therefore names the Python call it replaces (file:line under /root/reference) -- that call is what a
+ * maintainer re-points at this library (see INTEGRATION.md for the ctypes stubs).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only. Every device buffer (pixels, weights, workspace, outputs) is owned by the
+ *    caller (PyTorch allocator); the library owns only host-side descriptors.
+ *  - All device work is enqueued on the caller's hipStream_t (passed as void*) and is asynchronous; nothing
+ *    here synchronises the device or allocates device memory, so every call is hipGraph-capturable.
+ *  - Return value: 0 = ok, non-zero = error; merv_last_error() gives a thread-local message. No exceptions
+ *    cross the ABI.
+ *  - Activations and GEMM weights are bf16 (raw uint16 bits); biases, LayerNorm / LayerScale parameters,
+ *    temporal embeddings and the fusion vector are fp32.
+ */
+#ifndef MERV_HIP_H
+#define MERV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MERV_ABI_VERSION 1
+
+/* activation kinds */
+enum { MERV_ACT_NONE = 0, MERV_ACT_GELU_ERF = 1, MERV_ACT_GELU_TANH = 2, MERV_ACT_QUICK_GELU = 3 };
+/* pixel layouts */
+enum { MERV_PIX_BFCHW = 0 /* [B,F,3,H,W]: DINOv2, SigLIP, ViViT */, MERV_PIX_BCFHW = 1 /* [B,3,F,H,W]: LanguageBind */ };
+/* pixel dtypes */
+enum { MERV_DT_F32 = 0, MERV_DT_BF16 = 1 };
+
+/* Geometry / semantics of one visual encoder (SURVEY.md Appendix A lists the four instances). */
+typedef struct merv_encoder_desc {
+    int32_t dim;            /* embed dim D (1024 / 768) */
+    int32_t heads;          /* D / 64 */
+    int32_t mlp_dim;        /* 4096 / 3072 */
+    int32_t layers;         /* number of blocks actually run (23 / 23 / 12 / 11 for merv-full) */
+    int32_t patch;          /* spatial patch size (14 / 16) */
+    int32_t tubelet;        /* temporal patch size (2 for ViViT, else 1) */
+    int32_t img;            /* 224 */
+    int32_t frames;         /* input frames per video (16 / 16 / 32 / 16) */
+    int32_t pix_layout;     /* MERV_PIX_* */
+    int32_t prefix_tokens;  /* cls (+ register) tokens per sequence (1 / 5 / 1 / 0) */
+    int32_t joint_space_time; /* 1: one sequence per video over all tubelets (ViViT); 0: one per frame */
+    int32_t pre_ln;         /* LayerNorm right after the embeddings (LanguageBind pre_layrnorm) */
+    int32_t final_ln;       /* LayerNorm applied to the selected output (ViViT) */
+    int32_t layerscale;     /* LayerScale on both residual branches (DINOv2) */
+    int32_t temporal_frames;/* >0: temporal-attention sub-block over this many frames (LanguageBind: 8) */
+    int32_t act;            /* MERV_ACT_* of the MLP */
+    int32_t k_pad;          /* patch-embedding K padded to a multiple of 64 (588 -> 640) */
+    float ln_eps;
+} merv_encoder_desc;
+
+/* Per-block parameters. GEMM weights are nn.Linear-layout [out, in] bf16; q/k/v are concatenated row-wise. */
+typedef struct merv_layer_weights {
+    const float *ln1_w, *ln1_b;
+    const void *qkv_w;  const float *qkv_b;     /* [3D, D], [3D] */
+    const void *proj_w; const float *proj_b;    /* [D, D], [D] */
+    const float *ls1;                           /* [D] or NULL */
+    const float *ln2_w, *ln2_b;
+    const void *fc1_w;  const float *fc1_b;     /* [mlp, D] */
+    const void *fc2_w;  const float *fc2_b;     /* [D, mlp] */
+    const float *ls2;                           /* [D] or NULL */
+    /* temporal sub-block (LanguageBind, modeling_video.py:133-155); NULL otherwise */
+    const float *t_emb;                         /* [t, D] */
+    const float *t_ln_w, *t_ln_b;
+    const void *t_qkv_w; const float *t_qkv_b;
+    const void *t_proj_w; const float *t_proj_b;
+} merv_layer_weights;
+
+typedef struct merv_encoder_weights {
+    const void *patch_w;     /* [D, k_pad] bf16, conv kernel flattened (c, dt, dy, dx), zero padded */
+    const float *patch_b;    /* [D] or NULL (LanguageBind conv has no bias) */
+    const void *prefix;      /* [prefix_tokens, D] bf16: cls (+pos) / register rows, or NULL */
+    const void *pos;         /* [patches per sequence, D] bf16 position embedding of the patch tokens */
+    const float *pre_ln_w, *pre_ln_b;
+    const float *final_ln_w, *final_ln_b;
+    const merv_layer_weights *layers; /* [desc.layers] (host array, copied at create) */
+} merv_encoder_weights;
+
+typedef struct merv_encoder merv_encoder; /* opaque */
+
+/* Thread-local message for the last failing call on this thread. */
+const char *merv_last_error(void);
+int merv_abi_version(void);
+
+/*
+ * Frame-index sampler. Replaces the np.linspace(..., dtype=int) selection in
+ * merv/preprocessing/datasets/datasets.py:131-141 (and the NaN guards :46-52). Host-only, float64, bit-exact.
+ *   end_frame < 0  : ids = linspace(clip_start*fps, min(N-1, clip_end*fps - 1), n); clip_end_sec NaN = "None"
+ *   end_frame >= 0 : ids = linspace(0, min(N-1, end_frame), n)
+ */
+int merv_frame_indices(int64_t video_num_frames, double avg_fps, double clip_start_sec, double clip_end_sec,
+                       int64_t end_frame, int32_t num_frames, int64_t *out_ids);
+
+/* Per-encoder temporal subsample video[:: max_nf // nf] (merv.py:803-806). Returns count via *out_n. */
+int merv_temporal_subsample(int32_t loaded_frames, int32_t max_nf, int32_t nf, int32_t *out_idx, int32_t *out_n);
+
+/* Encoder lifecycle. Weight pointers are captured (not copied); they must outlive the encoder. */
+int merv_encoder_create(const merv_encoder_desc *desc, const merv_encoder_weights *w, merv_encoder **out);
+void merv_encoder_destroy(merv_encoder *enc);
+size_t merv_encoder_workspace_bytes(const merv_encoder *enc, int32_t batch);
+int32_t merv_encoder_num_patches(const merv_encoder *enc);   /* tokens returned per video */
+
+/*
+ * VideoBackbone.forward (languagebind/__init__.py:79-103, dinov2_video.py:132-154, vivit.py:100-118,
+ * siglip.py:142-151): pixels -> [B, num_patches, D] bf16 patch tokens (second-to-last block / final-LN rule per
+ * encoder, prefix tokens stripped).
+ */
+int merv_encoder_forward(const merv_encoder *enc, const void *pixels, int32_t pix_dtype, int32_t batch,
+                         void *out_tokens, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * AveragePooling3DProjector.forward with mlp_type="linear" (merv/util/nn_utils.py:320-330, :31-32):
+ * tokens [B, T*S*S, C] -> AdaptiveAvgPool3d((T, out_size, out_size)) -> Linear(C -> llm_dim) -> [B, T*out^2, llm_dim].
+ * pooled_ws: scratch of B*T*out^2*C bf16.
+ */
+int merv_projector_forward(const void *tokens, int32_t batch, int32_t T, int32_t S, int32_t C, int32_t out_size,
+                           const void *proj_w, const float *proj_b, int32_t llm_dim, void *pooled_ws, void *out,
+                           void *stream);
+
+/*
+ * CrossAttentionAdapterLearnableQuery.forward, averagetoken=True (merv/util/nn_utils.py:487-521).
+ * v[e]: [B, T, C] bf16; u = Wk^T (Wq Q + bq) / sqrt(embed_dim), fp32 [C] (folded by the host binding; the
+ * bk.q term is common to all encoders and cancels in the softmax). Outputs: out [B,T,C] bf16, weights [B,E] fp32.
+ * partial_ws: merv_fusion_workspace_floats(B,E,T) floats.
+ */
+size_t merv_fusion_workspace_floats(int32_t batch, int32_t num_encoders, int32_t T);
+int merv_fusion_forward(const void *const *v, int32_t num_encoders, int32_t batch, int32_t T, int32_t C,
+                        const float *u, float *partial_ws, float *weights_out, void *out, void *stream);
+
+/* Splice (merv/models/vidlms/merv.py:633-640): out[b] = cat(emb[b,:bos], vis[b], emb[b,bos:]) ; all bf16. */
+int merv_splice_forward(const void *emb, const void *vis, int32_t batch, int32_t S, int32_t T, int32_t C,
+                        int32_t bos, void *out, void *stream);
+
+/* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
+int merv_gemm_bf16(const void *A, const void *W, void *C, const float *bias, const float *lscale, const void *res,
+                   int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres,
+                   int32_t res_row_mod, int32_t out_group, int32_t out_stride, int32_t out_off, int32_t act,
+                   void *stream);
+int merv_layernorm(void *x, void *y, const float *gamma, const float *beta, const float *add, int32_t M, int32_t D,
+                   int32_t add_div, int32_t add_mod, float eps, void *stream);
+int merv_attention(const void *qkv, void *out, int32_t nseq, int32_t L, int32_t heads, int32_t D, float scale,
+                   void *stream);
+int merv_temporal_attention(const void *qkv, void *out, int32_t nclips, int32_t t, int32_t ntok, int32_t heads,
+                            int32_t D, float scale, void *stream);
+int merv_im2col(const void *pix, int32_t pix_dtype, void *out, int32_t B, int32_t frames, int32_t img, int32_t patch,
+                int32_t tubelet, int32_t k_pad, int64_t sB, int64_t sF, int64_t sC, void *stream);
+int merv_pool3d(const void *tokens, void *out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
+                void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERV_HIP_H */

@@ -1,0 +1,393 @@
+// Flash-style multi-head self attention, head_dim = 64, bf16 in / fp32 softmax / bf16 out (gfx950).
+//
+// Replaces the attention the reference reaches through timm `Attention` (F.scaled_dot_product_attention),
+// HF `CLIPAttention` (modeling_video.py:98,168) and HF `VivitSelfAttention` (vivit.py:104): no mask, no
+// dropout, softmax(q k^T / sqrt(64)) v. Sequences: LanguageBind 257, DINOv2 261, SigLIP 196 (many short
+// ones) and ViViT 3137 (one long one per video) -- the same kernel streams 64-key tiles with an online
+// softmax for all of them.
+//
+// Layout trick (cdna_hip_programming.md section 3, "An accumulator tile as the next MFMA's operand"):
+// scores are computed transposed, S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so each lane owns ONE query
+// (column = lane & 31) and 16 keys per 32-key block in its accumulator registers. Row max / row sum are then
+// in-lane reductions plus one cross-half exchange, the rescale factor is a per-lane scalar, and the
+// exponentiated tile is already in B-operand order for O^T = V^T P^T: no LDS round trip for P.
+// V^T fragments come either from a row-major V tile read with the hardware transpose load
+// (ds_read_b64_tr_b16, VTR = true) or from a tile transposed while staging (VTR = false).
+#include "common.h"
+#include "kernels.h"
+
+namespace merv {
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int HD = 64;               // head_dim
+constexpr int KROW = 128;            // bytes per K row in LDS
+constexpr int VROW_TR = 192;         // bytes per V row (row-major image for transposed reads; 192 keeps 4 rows on disjoint banks)
+constexpr int VT_ROW = 136;          // bytes per V^T row (64 keys + 8 B pad => conflict-free ds_read_b64)
+
+MERV_DEVICE int kswz(int key) { return (key >> 1) & 7; }  // 16 consecutive rows -> 16 distinct 16-B slots
+
+MERV_DEVICE bf16x8 join8(s16x4 a, s16x4 b) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+MERV_DEVICE bf16x8 pack8(const f32x16& s, int base) {
+    u32x4 w;
+    w[0] = pack2bf(s[base + 0], s[base + 1]);
+    w[1] = pack2bf(s[base + 2], s[base + 3]);
+    w[2] = pack2bf(s[base + 4], s[base + 5]);
+    w[3] = pack2bf(s[base + 6], s[base + 7]);
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// V^T A-operand fragment for O^T[d-block db] over the 16 keys starting at key_base (tile-local).
+// Element j of lane (r = lane & 31, h = lane >> 5) must be V[key_base + 8*(j>>2) + 4*h + (j&3)][db*32 + r].
+template <bool VTR>
+MERV_DEVICE bf16x8 load_vt_frag(const char* v_lds, int key_base, int db, int lane, int vrow_bytes) {
+    const int h = lane >> 5;
+    if constexpr (VTR) {
+        // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block; lane 4q+p supplies row q, cols 4p..4p+3;
+        // lane i of the group receives column i of the 4 rows.
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+        const int col = db * 32 + 16 * ((lane >> 4) & 1) + 4 * p4;
+        const char* a0 = v_lds + (key_base + 4 * h + q4) * vrow_bytes + col * 2;
+        const char* a1 = a0 + 8 * vrow_bytes;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        return join8(lo, hi);
+    } else {
+        const int r = lane & 31;
+        const char* a0 = v_lds + (db * 32 + r) * vrow_bytes + (key_base + 4 * h) * 2;
+        s16x4 lo = *(const s16x4*)a0;
+        s16x4 hi = *(const s16x4*)(a0 + 16);
+        return join8(lo, hi);
+    }
+}
+
+// Write two V rows (keys 2kp, 2kp+1; 8 d-values starting at 8c) transposed into V^T[d][key].
+MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u32x4 a, u32x4 b) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t lo = (a[w] & 0xffffu) | (b[w] << 16);
+        const uint32_t hi = (a[w] >> 16) | (b[w] & 0xffff0000u);
+        *(uint32_t*)(vt_lds + (8 * c + 2 * w) * vt_row_bytes + 4 * kp) = lo;
+        *(uint32_t*)(vt_lds + (8 * c + 2 * w + 1) * vt_row_bytes + 4 * kp) = hi;
+    }
+}
+
+template <bool VTR>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+    constexpr int V_BYTES = VTR ? 64 * VROW_TR : 64 * VT_ROW;
+    constexpr int VROWB = VTR ? VROW_TR : VT_ROW;
+    __shared__ __attribute__((aligned(16))) char smem[64 * KROW + V_BYTES];
+    char* k_lds = smem;
+    char* v_lds = smem + 64 * KROW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int seq = blockIdx.z, head = blockIdx.y;
+    const int L = p.L, D = p.D;
+    const int ld = 3 * D;
+    const bf16_t* base = p.qkv + (size_t)seq * L * ld;
+    const bf16_t* kbase = base + D + head * HD;
+    const bf16_t* vbase = base + 2 * D + head * HD;
+
+    const int q_row = blockIdx.x * 128 + wave * 32 + r;
+    const int q_ld = q_row < L ? q_row : L - 1;
+
+    // Q^T B-operand fragments: element j of step s = Q[q][16 s + 8 h + j]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * LOG2E;
+
+    // staging registers (issue global loads early, write LDS after the barrier)
+    u32x4 kreg[2], vreg[2];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            int key = kv0 + (idx >> 3);
+            key = key < L ? key : L - 1;
+            kreg[i] = *(const u32x4*)(kbase + (size_t)key * ld + (idx & 7) * 8);
+        }
+        if constexpr (VTR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;
+                int key = kv0 + (idx >> 3);
+                key = key < L ? key : L - 1;
+                vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + (idx & 7) * 8);
+            }
+        } else {
+            const int kp = tid >> 3, c = tid & 7;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int key = kv0 + 2 * kp + i;
+                key = key < L ? key : L - 1;
+                vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + c * 8);
+            }
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int key = idx >> 3, c = idx & 7;
+            *(u32x4*)(k_lds + key * KROW + ((c ^ kswz(key)) * 16)) = kreg[i];
+        }
+        if constexpr (VTR) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;
+                *(u32x4*)(v_lds + (idx >> 3) * VROW_TR + (idx & 7) * 16) = vreg[i];
+            }
+        } else {
+            write_vt_pair(v_lds, VT_ROW, tid >> 3, tid & 7, vreg[0], vreg[1]);
+        }
+    };
+
+    const int ntiles = (L + 63) / 64;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        __syncthreads();  // previous tile's LDS reads are done
+        write_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(kv0 + 64);
+
+        // ---- S^T = K Q^T (keys on rows, queries on lanes) ----
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+            const int key = kb * 32 + r;
+            const char* krow = k_lds + key * KROW;
+            const int sw = kswz(key);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (this lane: one query, 32 of the tile's 64 keys) ----
+        const bool tail = kv0 + 64 > L;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = sacc[kb][i] * sc;
+                if (tail) {
+                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (key >= L) v = -INFINITY;
+                }
+                sacc[kb][i] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = exp2f(sacc[kb][i] - m_new);
+                sacc[kb][i] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pf = pack8(sacc[kb], 8 * s2);
+                const int key_base = kb * 32 + 16 * s2;
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const bf16x8 vf = load_vt_frag<VTR>(v_lds, key_base, db, lane, VROWB);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < L) {
+        bf16_t* orow = p.out + ((size_t)seq * L + q_row) * D + head * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 o;
+                o[0] = pack2bf(oacc[db][4 * i + 0] * inv, oacc[db][4 * i + 1] * inv);
+                o[1] = pack2bf(oacc[db][4 * i + 2] * inv, oacc[db][4 * i + 3] * inv);
+                *(u32x2*)(orow + db * 32 + 8 * i + 4 * h) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LanguageBind temporal attention (modeling_video.py:133-155): for each (clip, token, head) attend over the
+// clip's t = 8 frames. Four such 8x8 problems are packed block-diagonally into one 32x32 MFMA tile per wave
+// (off-diagonal blocks masked to -inf), so the whole sub-block costs 8 MFMAs per 4 problems.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int TV_ROW_TR = 192;  // row-major V image per wave: 32 rows x 192 B
+constexpr int TVT_ROW = 72;     // V^T image per wave: 64 d-rows x (32 keys * 2 B + 8 B pad)
+
+template <bool VTR>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalAttnArgs p) {
+    constexpr int WAVE_LDS = VTR ? 32 * TV_ROW_TR : 64 * TVT_ROW;
+    constexpr int VROWB = VTR ? TV_ROW_TR : TVT_ROW;
+    __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_LDS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y;
+    const int D = p.D, ld = 3 * D;
+    const int NP = p.nclips * p.ntok;           // number of (clip, token) problems
+    const int pid0 = (blockIdx.x * 4 + wave) * 4;  // first of this wave's 4 problems
+    char* v_lds = smem + wave * WAVE_LDS;
+
+    auto row_of = [&](int idx) -> size_t {  // idx in [0,32): problem idx>>3, frame idx&7
+        int pid = pid0 + (idx >> 3);
+        pid = pid < NP ? pid : NP - 1;
+        const int clip = pid / p.ntok, tok = pid - clip * p.ntok;
+        return (size_t)(clip * 8 + (idx & 7)) * p.ntok + tok;
+    };
+    const size_t my_row = row_of(r);
+    const bf16_t* qrow = p.qkv + my_row * ld + head * HD;
+
+    bf16x8 qf[4], kf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *(const bf16x8*)(qrow + 16 * s + 8 * h);
+        kf[s] = *(const bf16x8*)(qrow + D + 16 * s + 8 * h);
+    }
+    // stage this wave's 32 V rows
+    if constexpr (VTR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            const int row = idx >> 3, c = idx & 7;
+            const u32x4 v = *(const u32x4*)(p.qkv + row_of(row) * ld + 2 * D + head * HD + c * 8);
+            *(u32x4*)(v_lds + row * TV_ROW_TR + c * 16) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kp = (lane >> 3) + 8 * i, c = lane & 7;
+            const u32x4 a = *(const u32x4*)(p.qkv + row_of(2 * kp) * ld + 2 * D + head * HD + c * 8);
+            const u32x4 b = *(const u32x4*)(p.qkv + row_of(2 * kp + 1) * ld + 2 * D + head * HD + c * 8);
+            write_vt_pair(v_lds, TVT_ROW, kp, c, a, b);
+        }
+    }
+
+    f32x16 sacc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], sacc, 0, 0, 0);
+
+    // this lane's query belongs to problem r>>3; key of register i is (i&3) + 8*(i>>2) + 4*h -> problem i>>2
+    const float sc = p.scale * LOG2E;
+    const int myp = r >> 3;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float v = ((i >> 2) == myp) ? sacc[i] * sc : -INFINITY;
+        sacc[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float e = exp2f(sacc[i] - mx);
+        sacc[i] = e;
+        psum += e;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    const float inv = 1.0f / psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sacc[i] *= inv;
+
+    __syncthreads();  // V image written (each wave only reads its own region)
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = pack8(sacc, 8 * s2);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const bf16x8 vf = load_vt_frag<VTR>(v_lds, 16 * s2, db, lane, VROWB);
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+        }
+    }
+    if (pid0 + myp < NP) {
+        bf16_t* orow = p.out + my_row * D + head * HD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 o;
+                o[0] = pack2bf(oacc[db][4 * i + 0], oacc[db][4 * i + 1]);
+                o[1] = pack2bf(oacc[db][4 * i + 2], oacc[db][4 * i + 3]);
+                *(u32x2*)(orow + db * 32 + 8 * i + 4 * h) = o;
+            }
+    }
+}
+
+}  // namespace
+
+// MERV_ATTN_VTR=0 in the environment selects the transposing-store V path (diagnostic switch, re-read per launch).
+static bool use_vtr() {
+    const char* e = getenv("MERV_ATTN_VTR");
+    return !(e && e[0] == '0');
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    if (a.nseq <= 0 || a.L <= 0) return hipSuccess;
+    if (a.D != a.heads * HD) return hipErrorInvalidValue;
+    dim3 grid((a.L + 127) / 128, a.heads, a.nseq);
+    if (use_vtr())
+        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {
+    if (a.nclips <= 0) return hipSuccess;
+    if (a.t != 8 || a.D != a.heads * HD) return hipErrorInvalidValue;
+    const int NP = a.nclips * a.ntok;
+    dim3 grid((NP + 15) / 16, a.heads);
+    if (use_vtr())
+        hipLaunchKernelGGL(temporal_attn_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(temporal_attn_kernel<false>, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace merv

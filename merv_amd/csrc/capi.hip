@@ -1,0 +1,341 @@
+// C-ABI of libmerv_hip.so (see include/merv_hip.h): argument checking, encoder orchestration (a stream-ordered
+// sequence of kernel launches per encoder, no allocation, no synchronisation) and thin kernel wrappers.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/merv_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace merv;
+
+static thread_local std::string g_err;
+extern "C" void merv_set_error(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" const char* merv_last_error(void) { return g_err.c_str(); }
+extern "C" int merv_abi_version(void) { return MERV_ABI_VERSION; }
+
+#define MERV_CHECK(cond, msg)        \
+    do {                             \
+        if (!(cond)) {               \
+            merv_set_error(msg);     \
+            return 1;                \
+        }                            \
+    } while (0)
+
+#define MERV_HIP(expr)                                                                  \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            char buf__[256];                                                            \
+            snprintf(buf__, sizeof buf__, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+            merv_set_error(buf__);                                                      \
+            return 2;                                                                   \
+        }                                                                               \
+    } while (0)
+
+struct merv_encoder {
+    merv_encoder_desc d;
+    merv_encoder_weights w;
+    std::vector<merv_layer_weights> layers;
+    // derived geometry
+    int hp;        // patches per side
+    int P;         // patch tokens per sequence
+    int ntok;      // tokens per sequence (prefix + P)
+    int seq_per_video;
+    int T_out;     // temporal resolution of the output (frames, or frames / tubelet for ViViT)
+    int S_out;     // spatial tokens per output frame
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int merv_encoder_create(const merv_encoder_desc* desc, const merv_encoder_weights* w, merv_encoder** out) {
+    MERV_CHECK(desc && w && out, "merv_encoder_create: null argument");
+    const merv_encoder_desc& d = *desc;
+    MERV_CHECK(d.dim > 0 && d.dim % 128 == 0 && d.heads * 64 == d.dim, "encoder: dim must be heads*64 and a multiple of 128");
+    MERV_CHECK(d.mlp_dim > 0 && d.mlp_dim % 128 == 0, "encoder: mlp_dim must be a multiple of 128");
+    MERV_CHECK(d.layers >= 0, "encoder: layers < 0");
+    MERV_CHECK(d.patch > 0 && d.img % d.patch == 0, "encoder: img must be a multiple of patch");
+    MERV_CHECK(d.tubelet >= 1 && d.frames >= 1 && d.frames % d.tubelet == 0, "encoder: frames must be a multiple of tubelet");
+    MERV_CHECK(d.k_pad % 64 == 0 && d.k_pad >= 3 * d.tubelet * d.patch * d.patch, "encoder: k_pad must be a multiple of 64 covering the patch");
+    MERV_CHECK(d.prefix_tokens >= 0, "encoder: prefix_tokens < 0");
+    MERV_CHECK(!d.joint_space_time || d.temporal_frames == 0, "encoder: temporal attention needs per-frame sequences");
+    MERV_CHECK(d.temporal_frames == 0 || (d.temporal_frames == 8 && d.frames % 8 == 0),
+               "encoder: temporal attention supports t == 8 with frames % 8 == 0");
+    MERV_CHECK(d.act >= MERV_ACT_NONE && d.act <= MERV_ACT_QUICK_GELU, "encoder: bad activation");
+    MERV_CHECK(w->patch_w && w->pos, "encoder: patch_w / pos missing");
+    MERV_CHECK(d.prefix_tokens == 0 || w->prefix, "encoder: prefix rows missing");
+    MERV_CHECK(!d.pre_ln || (w->pre_ln_w && w->pre_ln_b), "encoder: pre_ln weights missing");
+    MERV_CHECK(!d.final_ln || (w->final_ln_w && w->final_ln_b), "encoder: final_ln weights missing");
+    MERV_CHECK(d.layers == 0 || w->layers, "encoder: layer table missing");
+    for (int i = 0; i < d.layers; ++i) {
+        const merv_layer_weights& L = w->layers[i];
+        MERV_CHECK(L.ln1_w && L.ln1_b && L.qkv_w && L.qkv_b && L.proj_w && L.proj_b && L.ln2_w && L.ln2_b && L.fc1_w &&
+                       L.fc1_b && L.fc2_w && L.fc2_b,
+                   "encoder: a block weight is missing");
+        MERV_CHECK(!d.layerscale || (L.ls1 && L.ls2), "encoder: LayerScale weights missing");
+        MERV_CHECK(d.temporal_frames == 0 ||
+                       (L.t_emb && L.t_ln_w && L.t_ln_b && L.t_qkv_w && L.t_qkv_b && L.t_proj_w && L.t_proj_b),
+                   "encoder: temporal block weights missing");
+    }
+    merv_encoder* e = new merv_encoder();
+    e->d = d;
+    e->w = *w;
+    e->layers.assign(w->layers, w->layers + d.layers);
+    e->w.layers = e->layers.data();
+    e->hp = d.img / d.patch;
+    const int fo = d.frames / d.tubelet;
+    if (d.joint_space_time) {
+        e->P = fo * e->hp * e->hp;
+        e->seq_per_video = 1;
+    } else {
+        e->P = e->hp * e->hp;
+        e->seq_per_video = fo;
+    }
+    e->ntok = d.prefix_tokens + e->P;
+    e->T_out = fo;
+    e->S_out = e->hp * e->hp;
+    *out = e;
+    return 0;
+}
+
+extern "C" void merv_encoder_destroy(merv_encoder* enc) { delete enc; }
+
+extern "C" int32_t merv_encoder_num_patches(const merv_encoder* enc) { return enc ? enc->T_out * enc->S_out : 0; }
+
+namespace {
+struct Workspace {
+    bf16_t *x, *y, *qkv, *h;
+    size_t total;
+};
+Workspace carve(const merv_encoder* e, int batch, char* base) {
+    const size_t M = (size_t)batch * e->seq_per_video * e->ntok;
+    const size_t D = e->d.dim;
+    size_t hcols = e->d.mlp_dim;
+    if ((size_t)e->d.k_pad > hcols) hcols = e->d.k_pad;  // im2col matrix aliases the MLP hidden buffer
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += align_up(bytes, 256);
+        return (bf16_t*)p;
+    };
+    w.x = take(M * D * 2);
+    w.y = take(M * D * 2);
+    w.qkv = take(M * 3 * D * 2);
+    w.h = take(M * hcols * 2);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t merv_encoder_workspace_bytes(const merv_encoder* enc, int32_t batch) {
+    if (!enc || batch <= 0) return 0;
+    return carve(enc, batch, nullptr).total;
+}
+
+static GemmArgs gemm_args(const bf16_t* A, int lda, const void* W, int K, bf16_t* C, int ldc, int M, int N,
+                          const float* bias, int act) {
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = K; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act;
+    return g;
+}
+
+extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, int32_t pix_dtype, int32_t batch,
+                                    void* out_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
+    MERV_CHECK(e && pixels && out_tokens && workspace, "merv_encoder_forward: null argument");
+    MERV_CHECK(batch > 0, "merv_encoder_forward: batch must be positive");
+    MERV_CHECK(pix_dtype == MERV_DT_F32 || pix_dtype == MERV_DT_BF16, "merv_encoder_forward: bad pixel dtype");
+    MERV_CHECK(((uintptr_t)workspace & 255) == 0, "merv_encoder_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    const merv_encoder_desc& d = e->d;
+    Workspace ws = carve(e, batch, (char*)workspace);
+    MERV_CHECK(workspace_bytes >= ws.total, "merv_encoder_forward: workspace too small");
+
+    const int D = d.dim, nseq = batch * e->seq_per_video, ntok = e->ntok, M = nseq * ntok;
+    const float scale = 0.125f;  // 1/sqrt(64)
+
+    // ---- patch / tubelet embedding: im2col + GEMM (+bias +pos), rows scattered past the prefix tokens ----
+    {
+        Im2colArgs ic;
+        ic.pix = pixels; ic.pix_is_bf16 = (pix_dtype == MERV_DT_BF16); ic.out = ws.h;
+        ic.B = batch; ic.frames = d.frames; ic.img = d.img; ic.patch = d.patch; ic.tt = d.tubelet; ic.kpad = d.k_pad;
+        const long long hw = (long long)d.img * d.img;
+        if (d.pix_layout == MERV_PIX_BCFHW) { ic.sB = 3LL * d.frames * hw; ic.sC = d.frames * hw; ic.sF = hw; }
+        else { ic.sB = 3LL * d.frames * hw; ic.sF = 3 * hw; ic.sC = hw; }
+        MERV_HIP(launch_im2col(ic, s));
+        GemmArgs g = gemm_args(ws.h, d.k_pad, e->w.patch_w, d.k_pad, ws.x, D, nseq * e->P, D, e->w.patch_b, ACT_NONE);
+        g.res = (const bf16_t*)e->w.pos; g.ldres = D; g.res_row_mod = e->P;
+        g.out_group = e->P; g.out_stride = ntok; g.out_off = d.prefix_tokens;
+        MERV_HIP(launch_gemm(g, s));
+        if (d.prefix_tokens > 0) {
+            PrefixArgs pa{(const bf16_t*)e->w.prefix, ws.x, nseq, ntok, d.prefix_tokens, D};
+            MERV_HIP(launch_prefix(pa, s));
+        }
+        if (d.pre_ln) {
+            LayerNormArgs ln{ws.x, ws.x, e->w.pre_ln_w, e->w.pre_ln_b, nullptr, M, D, 1, 1, d.ln_eps};
+            MERV_HIP(launch_layernorm(ln, s));
+        }
+    }
+
+    // ---- transformer blocks ----
+    for (int li = 0; li < d.layers; ++li) {
+        const merv_layer_weights& L = e->layers[li];
+        if (d.temporal_frames > 0) {
+            // x += temporal_embedding[t]; x += out_proj(temporal_attn(LN_t(x)))   (modeling_video.py:133-155)
+            LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
+            MERV_HIP(launch_layernorm(ln, s));
+            GemmArgs q = gemm_args(ws.y, D, L.t_qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.t_qkv_b, ACT_NONE);
+            MERV_HIP(launch_gemm(q, s));
+            TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
+            MERV_HIP(launch_temporal_attention(ta, s));
+            GemmArgs o = gemm_args(ws.y, D, L.t_proj_w, D, ws.x, D, M, D, L.t_proj_b, ACT_NONE);
+            o.res = ws.x; o.ldres = D;
+            MERV_HIP(launch_gemm(o, s));
+        }
+        {
+            LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
+            MERV_HIP(launch_layernorm(ln, s));
+            GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
+            MERV_HIP(launch_gemm(q, s));
+            AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
+            MERV_HIP(launch_attention(at, s));
+            GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
+            o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
+            MERV_HIP(launch_gemm(o, s));
+        }
+        {
+            LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
+            MERV_HIP(launch_layernorm(ln, s));
+            GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
+            MERV_HIP(launch_gemm(f1, s));
+            GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
+            f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
+            MERV_HIP(launch_gemm(f2, s));
+        }
+    }
+
+    // ---- output selection: optional final LayerNorm, strip prefix tokens ----
+    const bf16_t* src = ws.x;
+    if (d.final_ln) {
+        LayerNormArgs ln{ws.x, ws.y, e->w.final_ln_w, e->w.final_ln_b, nullptr, M, D, 1, 1, d.ln_eps};
+        MERV_HIP(launch_layernorm(ln, s));
+        src = ws.y;
+    }
+    GatherTokensArgs ga;
+    ga.x = src; ga.out = (bf16_t*)out_tokens; ga.B = batch; ga.T = e->T_out; ga.S = e->S_out; ga.D = D;
+    ga.prefix = d.prefix_tokens;
+    if (d.joint_space_time) { ga.bstride = ntok; ga.fstride = e->S_out; }
+    else { ga.bstride = e->seq_per_video * ntok; ga.fstride = ntok; }
+    MERV_HIP(launch_gather_tokens(ga, s));
+    return 0;
+}
+
+extern "C" int merv_projector_forward(const void* tokens, int32_t batch, int32_t T, int32_t S, int32_t C,
+                                      int32_t out_size, const void* proj_w, const float* proj_b, int32_t llm_dim,
+                                      void* pooled_ws, void* out, void* stream_) {
+    MERV_CHECK(tokens && proj_w && pooled_ws && out, "merv_projector_forward: null argument");
+    MERV_CHECK(batch > 0 && T > 0 && S > 0 && out_size > 0 && S >= out_size, "merv_projector_forward: bad geometry");
+    MERV_CHECK(C % 64 == 0 && llm_dim % 128 == 0, "merv_projector_forward: C % 64 and llm_dim % 128 required");
+    hipStream_t s = (hipStream_t)stream_;
+    PoolArgs pa{(const bf16_t*)tokens, (bf16_t*)pooled_ws, batch, T, S, out_size, C};
+    MERV_HIP(launch_pool(pa, s));
+    const int M = batch * T * out_size * out_size;
+    GemmArgs g = gemm_args((const bf16_t*)pooled_ws, C, proj_w, C, (bf16_t*)out, llm_dim, M, llm_dim, proj_b, ACT_NONE);
+    MERV_HIP(launch_gemm(g, s));
+    return 0;
+}
+
+extern "C" size_t merv_fusion_workspace_floats(int32_t batch, int32_t E, int32_t T) {
+    if (batch <= 0 || E <= 0 || T <= 0) return 0;
+    return (size_t)fusion_partial_floats(batch, E, T);
+}
+
+extern "C" int merv_fusion_forward(const void* const* v, int32_t E, int32_t batch, int32_t T, int32_t C, const float* u,
+                                   float* partial_ws, float* weights_out, void* out, void* stream_) {
+    MERV_CHECK(v && u && partial_ws && weights_out && out, "merv_fusion_forward: null argument");
+    MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_forward: 1..8 encoders supported");
+    MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_forward: bad geometry");
+    FusionArgs fa;
+    memset(&fa, 0, sizeof fa);
+    for (int e = 0; e < E; ++e) {
+        MERV_CHECK(v[e], "merv_fusion_forward: null encoder tensor");
+        fa.v[e] = (const bf16_t*)v[e];
+    }
+    fa.E = E; fa.B = batch; fa.T = T; fa.C = C; fa.u = u; fa.partial = partial_ws; fa.weights = weights_out;
+    fa.out = (bf16_t*)out;
+    MERV_HIP(launch_fusion(fa, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_splice_forward(const void* emb, const void* vis, int32_t batch, int32_t S, int32_t T, int32_t C,
+                                   int32_t bos, void* out, void* stream_) {
+    MERV_CHECK(emb && vis && out, "merv_splice_forward: null argument");
+    MERV_CHECK(batch > 0 && S >= 0 && T >= 0 && C % 8 == 0 && bos >= 0 && bos <= S, "merv_splice_forward: bad geometry");
+    SpliceArgs sa{(const bf16_t*)emb, (const bf16_t*)vis, (bf16_t*)out, batch, S, T, C, bos};
+    MERV_HIP(launch_splice(sa, (hipStream_t)stream_));
+    return 0;
+}
+
+// ---- single-kernel wrappers ----
+extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* lscale,
+                              const void* res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
+                              int32_t ldres, int32_t res_row_mod, int32_t out_group, int32_t out_stride, int32_t out_off,
+                              int32_t act, void* stream_) {
+    MERV_CHECK(A && W && C, "merv_gemm_bf16: null argument");
+    MERV_CHECK(K > 0 && K % 64 == 0 && N > 0 && N % 128 == 0, "merv_gemm_bf16: K % 64 == 0 and N % 128 == 0 required");
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C; g.bias = bias; g.lscale = lscale;
+    g.res = (const bf16_t*)res; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldres = ldres;
+    g.res_row_mod = res_row_mod; g.out_group = out_group; g.out_stride = out_stride; g.out_off = out_off; g.act = act;
+    MERV_HIP(launch_gemm(g, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_layernorm(void* x, void* y, const float* gamma, const float* beta, const float* add, int32_t M,
+                              int32_t D, int32_t add_div, int32_t add_mod, float eps, void* stream_) {
+    MERV_CHECK(x && y && gamma && beta, "merv_layernorm: null argument");
+    LayerNormArgs ln{(bf16_t*)x, (bf16_t*)y, gamma, beta, add, M, D, add_div, add_mod, eps};
+    MERV_HIP(launch_layernorm(ln, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_attention(const void* qkv, void* out, int32_t nseq, int32_t L, int32_t heads, int32_t D, float scale,
+                              void* stream_) {
+    MERV_CHECK(qkv && out, "merv_attention: null argument");
+    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)out, nseq, L, heads, D, scale};
+    MERV_HIP(launch_attention(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_temporal_attention(const void* qkv, void* out, int32_t nclips, int32_t t, int32_t ntok, int32_t heads,
+                                       int32_t D, float scale, void* stream_) {
+    MERV_CHECK(qkv && out, "merv_temporal_attention: null argument");
+    TemporalAttnArgs a{(const bf16_t*)qkv, (bf16_t*)out, nclips, t, ntok, heads, D, scale};
+    MERV_HIP(launch_temporal_attention(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_im2col(const void* pix, int32_t pix_dtype, void* out, int32_t B, int32_t frames, int32_t img,
+                           int32_t patch, int32_t tubelet, int32_t k_pad, int64_t sB, int64_t sF, int64_t sC,
+                           void* stream_) {
+    MERV_CHECK(pix && out, "merv_im2col: null argument");
+    Im2colArgs ic;
+    ic.pix = pix; ic.pix_is_bf16 = (pix_dtype == MERV_DT_BF16); ic.out = (bf16_t*)out; ic.B = B; ic.frames = frames;
+    ic.img = img; ic.patch = patch; ic.tt = tubelet; ic.kpad = k_pad; ic.sB = sB; ic.sF = sF; ic.sC = sC;
+    MERV_HIP(launch_im2col(ic, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_pool3d(const void* tokens, void* out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
+                           void* stream_) {
+    MERV_CHECK(tokens && out, "merv_pool3d: null argument");
+    PoolArgs pa{(const bf16_t*)tokens, (bf16_t*)out, B, T, S, out_size, C};
+    MERV_HIP(launch_pool(pa, (hipStream_t)stream_));
+    return 0;
+}

@@ -1,0 +1,74 @@
+// Common device/host helpers for the MERV multi-encoder video forward path on gfx950 (MI355X).
+// Everything here is written for CDNA4 only: 64-lane wavefronts, bf16 MFMA, LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace merv {
+
+typedef uint16_t bf16_t;  // raw bf16 bits; all activations / GEMM weights are stored this way
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MERV_DEVICE __device__ __forceinline__
+
+// f32 -> bf16, round-to-nearest-even. A plain cast lowers to v_cvt_pk_bf16_f32 at -O3 and keeps
+// NaNs NaN (MI355X_MICROARCH "Correctness boundaries").
+MERV_DEVICE bf16_t f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(bf16_t, b);
+}
+MERV_DEVICE float bf2f(bf16_t x) { return __builtin_bit_cast(float, ((uint32_t)x) << 16); }
+MERV_DEVICE uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+MERV_DEVICE float bflo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+MERV_DEVICE float bfhi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// Activation kinds (ABI values, see include/merv_hip.h).
+enum : int { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_QUICK_GELU = 3 };
+
+template <int ACT>
+MERV_DEVICE float activate(float x) {
+    if constexpr (ACT == ACT_GELU_ERF) {
+        // timm nn.GELU (exact erf form)
+        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    } else if constexpr (ACT == ACT_GELU_TANH) {
+        // HF "gelu_fast": 0.5x(1+tanh(0.7978845608 x (1+0.044715 x^2)))
+        float u = 0.7978845608f * x * (1.0f + 0.044715f * x * x);
+        // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly at +-1 for |u| large
+        float e = __expf(2.0f * u);
+        float t = 1.0f - 2.0f / (e + 1.0f);
+        return 0.5f * x * (1.0f + t);
+    } else if constexpr (ACT == ACT_QUICK_GELU) {
+        // CLIP quick_gelu: x * sigmoid(1.702 x)
+        return x / (1.0f + __expf(-1.702f * x));
+    } else {
+        return x;
+    }
+}
+
+MERV_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MERV_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id (cdna_hip_programming.md section 5, "XCD swizzle must be
+// bijective"): blocks that share an XCD (b % 8 equal) get a contiguous chunk of the logical grid, so
+// neighbouring tiles share operand panels in one XCD's L2. Speed only, never correctness.
+MERV_DEVICE int xcd_remap(int orig, int nwg) {
+    const int xcd = orig & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+}  // namespace merv

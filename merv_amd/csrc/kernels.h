@@ -1,0 +1,120 @@
+// Internal kernel launch interface (not part of the C-ABI; see include/merv_hip.h for that).
+#pragma once
+#include "common.h"
+
+namespace merv {
+
+struct GemmArgs {
+    const bf16_t* A;      // [M, K] bf16, leading dim lda
+    const bf16_t* W;      // [N, K] bf16 (nn.Linear layout), leading dim ldw
+    bf16_t* C;            // [*, N] bf16, leading dim ldc
+    const float* bias;    // [N] fp32 or nullptr
+    const float* lscale;  // [N] fp32 LayerScale gamma or nullptr (applied after activation, before residual)
+    const bf16_t* res;    // residual / position embedding (bf16) or nullptr, leading dim ldres
+    int M, N, K;
+    int lda, ldw, ldc, ldres;
+    int res_row_mod;  // >0: residual row = m % res_row_mod (position-embedding add in patch embedding)
+    int out_group;    // >0: output row = (m / out_group) * out_stride + out_off + (m % out_group)
+    int out_stride;
+    int out_off;
+    int act;          // ACT_*
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// Row LayerNorm (fp32 statistics), optional fused "x += add[(row / add_div) % add_mod]" written back in place
+// (LanguageBind temporal embedding, modeling_video.py:138-141).
+struct LayerNormArgs {
+    bf16_t* x;            // [M, D] bf16 (updated in place only when add != nullptr)
+    bf16_t* y;            // [M, D] bf16 normalised output (may alias x when add == nullptr)
+    const float* gamma;   // [D]
+    const float* beta;    // [D]
+    const float* add;     // [add_mod, D] fp32 or nullptr
+    int M, D;
+    int add_div, add_mod;
+    float eps;
+};
+hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
+
+// Multi-head self attention over packed QKV rows: qkv[row][{q,k,v} * D + head * 64 + d], head_dim = 64.
+// Sequence s covers rows [s*L, (s+1)*L). out[row][head*64 + d].
+struct AttnArgs {
+    const bf16_t* qkv;  // [nseq*L, 3*D]
+    bf16_t* out;        // [nseq*L, D]
+    int nseq, L, heads, D;
+    float scale;        // 1/sqrt(head_dim)
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// LanguageBind temporal attention: for every (clip, token, head) an 8x8 attention over the clip's t frames.
+// Rows are frame-major: row = frame * ntok + token, frame = clip * t + i (modeling_video.py:133-155).
+struct TemporalAttnArgs {
+    const bf16_t* qkv;  // [nclips*t*ntok, 3*D]
+    bf16_t* out;        // [nclips*t*ntok, D]
+    int nclips, t, ntok, heads, D;
+    float scale;
+};
+hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s);
+
+// im2col for Conv2d(k=s=p) / Conv3d(k=s=(tt,p,p)) patch embedding. Output A[m][k] bf16 with
+// m = ((b*Fo + fo)*Hp + py)*Wp + px and k = ((c*tt + dt)*p + dy)*p + dx, zero padded to kpad.
+struct Im2colArgs {
+    const void* pix;   // fp32 or bf16 pixels
+    int pix_is_bf16;
+    bf16_t* out;       // [B*Fo*Hp*Wp, kpad]
+    int B, frames, img, patch, tt, kpad;
+    long long sB, sF, sC;  // element strides of batch / frame / channel in `pix` (row stride = img, col stride = 1)
+};
+hipError_t launch_im2col(const Im2colArgs& a, hipStream_t s);
+
+// Broadcast prefix token rows (cls / register tokens, position already folded in) into every sequence.
+struct PrefixArgs {
+    const bf16_t* prefix;  // [npre, D]
+    bf16_t* x;             // [nseq*ntok, D]
+    int nseq, ntok, npre, D;
+};
+hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s);
+
+// Strip prefix tokens: out[b][f*S + s][:] = x[row(b,f) + s][:], row(b,f) = b*bstride + f*fstride + prefix.
+// (VideoBackbone.forward output contract, [B, num_patches, embed_dim]).
+struct GatherTokensArgs {
+    const bf16_t* x;
+    bf16_t* out;
+    int B, T, S, D;
+    int bstride, fstride, prefix;
+};
+hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s);
+
+// AdaptiveAvgPool3d((T, Ho, Ho)) over tokens laid out [B, T, S*S, C] (nn_utils.py:320-328); T is kept
+// (output_frames == temporal_resolution for 3davg), spatial S -> Ho with torch's window rule
+// [floor(i*S/Ho), ceil((i+1)*S/Ho)). Output [B*T*Ho*Ho, C] bf16.
+struct PoolArgs {
+    const bf16_t* x;   // [B, T*S*S, C] contiguous tokens (prefix already stripped)
+    bf16_t* out;
+    int B, T, S, Ho, C;
+};
+hipError_t launch_pool(const PoolArgs& a, hipStream_t s);
+
+// Cross-encoder fusion (nn_utils.py:487-521, averagetoken=True): score[b][e] = mean_t(V_e[b][t]) . u,
+// w = softmax_e(score), out = sum_e w_e V_e. u = Wk^T (Wq Q + bq) / sqrt(embed_dim) is folded on the host.
+struct FusionArgs {
+    const bf16_t* v[8];   // E tensors [B, T, C]
+    int E, B, T, C;
+    const float* u;       // [C]
+    float* partial;       // workspace [B*E*nchunk]
+    float* weights;       // [B, E] fp32 out
+    bf16_t* out;          // [B, T, C]
+};
+hipError_t launch_fusion(const FusionArgs& a, hipStream_t s);
+int fusion_partial_floats(int B, int E, int T);
+
+// Splice fused visual tokens after the BOS embedding (merv.py:633-640):
+// out[b] = cat(emb[b, :bos], vis[b], emb[b, bos:]).
+struct SpliceArgs {
+    const bf16_t* emb;  // [B, S, C]
+    const bf16_t* vis;  // [B, T, C]
+    bf16_t* out;        // [B, S+T, C]
+    int B, S, T, C, bos;
+};
+hipError_t launch_splice(const SpliceArgs& a, hipStream_t s);
+
+}  // namespace merv

@@ -1,0 +1,336 @@
+// HBM-bound row kernels of the MERV visual path (gfx950): LayerNorm, im2col, prefix-token broadcast,
+// token gather, adaptive 3-D average pool, cross-encoder fusion and the BOS splice. All of them move
+// 16 bytes per lane (cdna_hip_programming.md Guideline 13) and keep statistics in fp32.
+#include "common.h"
+#include "kernels.h"
+
+namespace merv {
+namespace {
+
+MERV_DEVICE void unpack8(u32x4 v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bflo(v[i]); f[2 * i + 1] = bfhi(v[i]); }
+}
+MERV_DEVICE u32x4 pack8f(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, D <= 1536 (D % 8 == 0). Two-pass statistics in registers.
+// timm / HF ViT blocks: nn.LayerNorm(eps 1e-6); LanguageBind: config.layer_norm_eps (modeling_video.py:99-101).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LN_MAX_CHUNKS = 3;  // 3 * 64 lanes * 8 elements = 1536
+
+__global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nchunk = p.D >> 3;
+    float v[LN_MAX_CHUNKS][8];
+    bf16_t* xr = p.x + (size_t)row * p.D;
+    const float* addr = p.add ? p.add + (size_t)((row / p.add_div) % p.add_mod) * p.D : nullptr;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            unpack8(*(const u32x4*)(xr + c * 8), v[i]);
+            if (addr) {
+                const float4 a0 = *(const float4*)(addr + c * 8), a1 = *(const float4*)(addr + c * 8 + 4);
+                v[i][0] += a0.x; v[i][1] += a0.y; v[i][2] += a0.z; v[i][3] += a0.w;
+                v[i][4] += a1.x; v[i][5] += a1.y; v[i][6] += a1.z; v[i][7] += a1.w;
+                // the residual stream is bf16: round once, write back, and normalise the rounded values
+                const u32x4 r = pack8f(v[i]);
+                *(u32x4*)(xr + c * 8) = r;
+                unpack8(r, v[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    bf16_t* yr = p.y + (size_t)row * p.D;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            const float4 g0 = *(const float4*)(p.gamma + c * 8), g1 = *(const float4*)(p.gamma + c * 8 + 4);
+            const float4 b0 = *(const float4*)(p.beta + c * 8), b1 = *(const float4*)(p.beta + c * 8 + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
+            *(u32x4*)(yr + c * 8) = pack8f(o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// im2col: one thread per 8 output elements (16 B store). Replaces the unfold inside Conv2d / Conv3d patch
+// embedding (timm PatchEmbed, HF CLIPVisionEmbeddings, HF VivitTubeletEmbeddings).
+// ---------------------------------------------------------------------------------------------------------
+template <bool BF16_IN>
+__global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs p) {
+    const int hp = p.img / p.patch;
+    const int fo = p.frames / p.tt;
+    const int kc = p.kpad >> 3;
+    const long long total = (long long)p.B * fo * hp * hp * kc;
+    const int ktrue = 3 * p.tt * p.patch * p.patch;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int kchunk = (int)(g % kc);
+        long long m = g / kc;
+        const int px = (int)(m % hp); m /= hp;
+        const int py = (int)(m % hp); m /= hp;
+        const int f = (int)(m % fo);
+        const int b = (int)(m / fo);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kchunk * 8 + j;
+            float val = 0.f;
+            if (k < ktrue) {
+                int t = k;
+                const int dx = t % p.patch; t /= p.patch;
+                const int dy = t % p.patch; t /= p.patch;
+                const int dt = t % p.tt;
+                const int c = t / p.tt;
+                const long long off = b * p.sB + (long long)(f * p.tt + dt) * p.sF + c * p.sC +
+                                      (long long)(py * p.patch + dy) * p.img + (px * p.patch + dx);
+                if constexpr (BF16_IN) val = bf2f(((const bf16_t*)p.pix)[off]);
+                else val = ((const float*)p.pix)[off];
+            }
+            o[j] = val;
+        }
+        *(u32x4*)(p.out + (g << 3)) = pack8f(o);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prefix_kernel(PrefixArgs p) {
+    const int dc = p.D >> 3;
+    const int total = p.nseq * p.npre * dc;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < total; g += gridDim.x * 256) {
+        const int c = g % dc;
+        const int t = (g / dc) % p.npre;
+        const int s = g / (dc * p.npre);
+        *(u32x4*)(p.x + ((size_t)s * p.ntok + t) * p.D + c * 8) = *(const u32x4*)(p.prefix + (size_t)t * p.D + c * 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_tokens_kernel(GatherTokensArgs p) {
+    const int dc = p.D >> 3;
+    const long long total = (long long)p.B * p.T * p.S * dc;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int c = (int)(g % dc);
+        long long m = g / dc;
+        const int s = (int)(m % p.S); m /= p.S;
+        const int f = (int)(m % p.T);
+        const int b = (int)(m / p.T);
+        const size_t src = (size_t)b * p.bstride + (size_t)f * p.fstride + p.prefix + s;
+        *(u32x4*)(p.out + (g << 3)) = *(const u32x4*)(p.x + src * p.D + c * 8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// AdaptiveAvgPool3d((T, Ho, Ho)) with T unchanged. One thread per (output token, 8 channels).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs p) {
+    const int dc = p.C >> 3;
+    const long long total = (long long)p.B * p.T * p.Ho * p.Ho * dc;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int c = (int)(g % dc);
+        long long m = g / dc;
+        const int ox = (int)(m % p.Ho); m /= p.Ho;
+        const int oy = (int)(m % p.Ho); m /= p.Ho;  // m = b*T + f
+        const int y0 = (oy * p.S) / p.Ho, y1 = ((oy + 1) * p.S + p.Ho - 1) / p.Ho;
+        const int x0 = (ox * p.S) / p.Ho, x1 = ((ox + 1) * p.S + p.Ho - 1) / p.Ho;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16_t* base = p.x + ((size_t)m * p.S * p.S) * p.C + c * 8;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                float f[8];
+                unpack8(*(const u32x4*)(base + (size_t)(y * p.S + x) * p.C), f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= inv;
+        *(u32x4*)(p.out + (g << 3)) = pack8f(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fusion. Pass 1: partial[b][e][chunk] = sum over FUSE_ROWS tokens of (V_e[b][t] . u). Pass 2: every block
+// re-reduces the partials of its batch item in a fixed order (deterministic), softmaxes over encoders and
+// writes out = sum_e w_e V_e for its token rows.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FUSE_ROWS = 16;  // tokens per pass-1 block
+
+__global__ __launch_bounds__(256) void fusion_score_kernel(FusionArgs p) {
+    const int nchunk = (p.T + FUSE_ROWS - 1) / FUSE_ROWS;
+    const int chunk = blockIdx.x, e = blockIdx.y, b = blockIdx.z;
+    const bf16_t* v = p.v[e] + (size_t)b * p.T * p.C;
+    const int dc = p.C >> 3;
+    float acc = 0.f;
+    const int t_end = min(p.T, (chunk + 1) * FUSE_ROWS);
+    for (int t = chunk * FUSE_ROWS; t < t_end; ++t)
+        for (int c = threadIdx.x; c < dc; c += 256) {
+            float f[8];
+            unpack8(*(const u32x4*)(v + (size_t)t * p.C + c * 8), f);
+            const float4 u0 = *(const float4*)(p.u + c * 8), u1 = *(const float4*)(p.u + c * 8 + 4);
+            acc += f[0] * u0.x + f[1] * u0.y + f[2] * u0.z + f[3] * u0.w + f[4] * u1.x + f[5] * u1.y + f[6] * u1.z +
+                   f[7] * u1.w;
+        }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[((size_t)b * p.E + e) * nchunk + chunk] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void fusion_mix_kernel(FusionArgs p) {
+    const int nchunk = (p.T + FUSE_ROWS - 1) / FUSE_ROWS;
+    const int b = blockIdx.y;
+    __shared__ float w_s[8];
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        float sc[8];
+        float mx = -INFINITY;
+        for (int e = 0; e < p.E; ++e) {
+            float a = 0.f;
+            for (int c = lane; c < nchunk; c += 64) a += p.partial[((size_t)b * p.E + e) * nchunk + c];
+            a = wave_sum(a) / (float)p.T;
+            sc[e] = a;
+            mx = fmaxf(mx, a);
+        }
+        float den = 0.f;
+        for (int e = 0; e < p.E; ++e) { sc[e] = __expf(sc[e] - mx); den += sc[e]; }
+        if (lane == 0)
+            for (int e = 0; e < p.E; ++e) {
+                const float w = sc[e] / den;
+                w_s[e] = w;
+                if (blockIdx.x == 0) p.weights[b * p.E + e] = w;
+            }
+    }
+    __syncthreads();
+    const int dc = p.C >> 3;
+    const long long per_b = (long long)p.T * dc;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < per_b; g += (long long)gridDim.x * 256) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const size_t off = (size_t)b * p.T * p.C + (size_t)g * 8;
+        for (int e = 0; e < p.E; ++e) {
+            float f[8];
+            unpack8(*(const u32x4*)(p.v[e] + off), f);
+            const float w = w_s[e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * f[j];
+        }
+        *(u32x4*)(p.out + off) = pack8f(acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void splice_kernel(SpliceArgs p) {
+    const int dc = p.C >> 3;
+    const int So = p.S + p.T;
+    const long long total = (long long)p.B * So * dc;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int c = (int)(g % dc);
+        long long m = g / dc;
+        const int t = (int)(m % So);
+        const int b = (int)(m / So);
+        const bf16_t* src;
+        if (t < p.bos) src = p.emb + ((size_t)b * p.S + t) * p.C;
+        else if (t < p.bos + p.T) src = p.vis + ((size_t)b * p.T + (t - p.bos)) * p.C;
+        else src = p.emb + ((size_t)b * p.S + (t - p.T)) * p.C;
+        *(u32x4*)(p.out + (g << 3)) = *(const u32x4*)(src + c * 8);
+    }
+}
+
+inline int grid_for(long long items) {
+    long long g = (items + 255) / 256;
+    if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest (Guideline 11)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.D % 8 != 0 || a.D > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
+    if (a.add && (a.add_div <= 0 || a.add_mod <= 0)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col(const Im2colArgs& a, hipStream_t s) {
+    if (a.kpad % 8 != 0 || a.img % a.patch != 0 || a.frames % a.tt != 0) return hipErrorInvalidValue;
+    const int hp = a.img / a.patch;
+    const long long total = (long long)a.B * (a.frames / a.tt) * hp * hp * (a.kpad / 8);
+    if (total <= 0) return hipSuccess;
+    if (a.pix_is_bf16)
+        hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(im2col_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
+    const long long total = (long long)a.nseq * a.npre * (a.D / 8);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(prefix_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s) {
+    const long long total = (long long)a.B * a.T * a.S * (a.D / 8);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool(const PoolArgs& a, hipStream_t s) {
+    if (a.C % 8 != 0 || a.Ho <= 0 || a.S < a.Ho) return hipErrorInvalidValue;
+    const long long total = (long long)a.B * a.T * a.Ho * a.Ho * (a.C / 8);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+int fusion_partial_floats(int B, int E, int T) { return B * E * ((T + FUSE_ROWS - 1) / FUSE_ROWS); }
+
+hipError_t launch_fusion(const FusionArgs& a, hipStream_t s) {
+    if (a.E < 1 || a.E > 8 || a.C % 8 != 0) return hipErrorInvalidValue;
+    if (a.B <= 0) return hipSuccess;
+    const int nchunk = (a.T + FUSE_ROWS - 1) / FUSE_ROWS;
+    hipLaunchKernelGGL(fusion_score_kernel, dim3(nchunk, a.E, a.B), dim3(256), 0, s, a);
+    const long long per_b = (long long)a.T * (a.C / 8);
+    int gx = (int)((per_b + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(fusion_mix_kernel, dim3(gx, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_splice(const SpliceArgs& a, hipStream_t s) {
+    const long long total = (long long)a.B * (a.S + a.T) * (a.C / 8);
+    if (total <= 0 || a.C % 8 != 0) return total <= 0 ? hipSuccess : hipErrorInvalidValue;
+    hipLaunchKernelGGL(splice_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace merv

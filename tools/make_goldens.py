@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""
+make_goldens.py -- generates tests/golden/* by running the REFERENCE's own code in this container.
+
+Runs only where /root/reference exists (the build container); the GPU box and the test-suite use the committed
+fixtures. Nothing of the reference's source is copied: the script imports reference modules *by file path* with
+tiny stubs for packages the image lacks (timm, peft) and stores input/output vectors only.
+
+What is pinned, and against what:
+  frame_indices.json   numpy.linspace(..., dtype=int) evaluated with the argument expressions of
+                       merv/preprocessing/datasets/datasets.py:131-141 (decord itself is absent, so the two
+                       np.linspace call sites are evaluated directly), incl. eval_data/dummy_mcq end_frame=595.
+  projector_fusion.npz the reference's AveragePooling3DProjector / CrossAttentionAdapterLearnableQuery
+                       (merv/util/nn_utils.py, imported by path) -- inputs, state dicts, outputs.
+  languagebind.npz     the reference's vendored CLIPVisionTransformer (languagebind/video/modeling_video.py, imported
+                       by path; composes the installed transformers' CLIPAttention/CLIPMLP/CLIPVisionEmbeddings),
+                       2 layers, D=128, T=16 frames with config.num_frames=8 -> hidden_states[-2].
+  vivit.npz            transformers.VivitModel (the class vivit.py:42 instantiates), reduced size, last_hidden_state.
+  hf_crosscheck.npz    HF Dinov2WithRegistersModel / SiglipVisionModel reduced-size hidden states: a cross-check for
+                       the timm-semantics restatement (timm itself is not installed: "timm parity unpinned").
+  prompts.json         PurePromptBuilder strings (merv/models/backbones/llm/prompting/base_prompter.py).
+"""
+import importlib.util
+import json
+import math
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+
+
+def _load(name, path, package=None):
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=None)
+    mod = importlib.util.module_from_spec(spec)
+    if package:
+        mod.__package__ = package
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ----------------------------------------------------------------------------------------------------------
+def gen_frame_indices():
+    cases = []
+
+    def add(N, fps, start, end, n, end_frame):
+        # datasets.py:46-52
+        cs, ce = start, end
+        if cs is not None and math.isnan(cs):
+            cs = 0
+        if ce is not None and math.isnan(ce):
+            ce = None
+        total_secs = N / fps
+        if end_frame is None or end_frame < 0:  # :131-137
+            if ce is None:
+                ce = total_secs
+            ids = np.linspace(cs * fps, min(N - 1, ce * fps - 1), n, dtype=int)
+        else:  # :138-141
+            ids = np.linspace(0, min(N - 1, end_frame), n, dtype=int)
+        cases.append({"N": N, "fps": fps, "clip_start_sec": start, "clip_end_sec": end, "num_frames": n,
+                      "end_frame": end_frame, "ids": [int(i) for i in ids]})
+
+    add(596, 29.97, 0.0, None, 32, 595)  # eval_data/dummy_mcq/test_q.json
+    add(596, 29.97, 0.0, None, 32, None)
+    add(596, 30.0, 0.0, None, 32, -1)
+    add(300, 25.0, 0.0, None, 8, None)
+    add(300, 25.0, 2.0, 7.5, 16, None)
+    add(1000, 23.976023976023978, 1.5, 30.25, 32, None)
+    add(1000, 23.976023976023978, 0.0, 100.0, 32, None)  # clip end beyond the video -> clamps to N-1
+    add(20, 30.0, 0.0, None, 32, None)  # fewer frames than samples (repeats)
+    add(1, 30.0, 0.0, None, 4, None)  # single frame: step == 0 branch
+    add(33, 29.97, 0.0, None, 32, None)
+    add(5000, 59.94, 10.0, 20.0, 32, None)
+    add(5000, 59.94, float("nan"), float("nan"), 32, None)  # TVQA NaN pair
+    add(5000, 59.94, 3.0, float("nan"), 16, None)
+    add(240, 24.0, 0.0, None, 1, None)  # num=1
+    add(240, 24.0, 0.0, None, 32, 100000)  # end_frame beyond the video
+    add(240, 24.0, 0.0, None, 32, 0)
+    add(240, 24.0, 5.0, None, 32, 17)
+    add(12345, 29.97002997002997, 0.0, None, 32, None)
+    add(901, 15.0, 0.0, 60.0, 32, None)
+    add(901, 15.0, 59.0, 60.0, 32, None)
+    rng = np.random.RandomState(0)
+    for _ in range(60):
+        N = int(rng.randint(2, 20000))
+        fps = float(rng.choice([23.976023976023978, 24.0, 25.0, 29.97, 29.97002997002997, 30.0, 59.94, 60.0, 12.5]))
+        total = N / fps
+        s = float(rng.uniform(0, total * 0.6))
+        e = float(rng.uniform(s + 0.05, total * 1.1))
+        n = int(rng.choice([4, 8, 16, 32]))
+        mode = rng.randint(3)
+        if mode == 0:
+            add(N, fps, s, e, n, None)
+        elif mode == 1:
+            add(N, fps, 0.0, None, n, None)
+        else:
+            add(N, fps, 0.0, None, n, int(rng.randint(0, N + 50)))
+    (OUT / "frame_indices.json").write_text(json.dumps(cases, indent=0))
+    print("frame_indices:", len(cases), "cases")
+
+
+# ----------------------------------------------------------------------------------------------------------
+def _stub_timm():
+    timm = types.ModuleType("timm")
+    layers = types.ModuleType("timm.layers")
+    models = types.ModuleType("timm.models")
+    regnet = types.ModuleType("timm.models.regnet")
+    layers.LayerNorm2d = torch.nn.LayerNorm
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    regnet.RegStage = object
+    sys.modules.update({"timm": timm, "timm.layers": layers, "timm.models": models, "timm.models.regnet": regnet})
+
+
+def gen_projector_fusion():
+    _stub_timm()
+    nn_utils = _load("ref_nn_utils", REF / "merv/util/nn_utils.py")
+    torch.manual_seed(1024)  # merv.py:87 seeds with video_backbones[0].embed_dim
+    out = {}
+    # reduced-width projector, both spatial geometries (16->8 exact 2x2, 14->8 overlapping windows)
+    for tag, S, C in (("s16", 16, 64), ("s14", 14, 48)):
+        T, llm, B = 16, 128, 2
+        proj = nn_utils.AveragePooling3DProjector(C, llm, output_frames=T, output_size=8, mlp_type="linear").eval()
+        x = torch.randn(B, T, S * S, C)
+        with torch.no_grad():
+            y = proj(x)
+        sd = proj.state_dict()
+        out[f"proj_{tag}_keys"] = np.array(sorted(sd.keys()))
+        out[f"proj_{tag}_x"] = x.numpy()
+        out[f"proj_{tag}_w"] = sd["projector.projector.weight"].numpy()
+        out[f"proj_{tag}_b"] = sd["projector.projector.bias"].numpy()
+        out[f"proj_{tag}_y"] = y.numpy()
+    # full-width single-batch slice: first 4 output tokens only (keeps the fixture small)
+    proj = nn_utils.AveragePooling3DProjector(768, 4096, output_frames=16, output_size=8, mlp_type="linear").eval()
+    x = torch.randn(1, 16, 196, 768)
+    with torch.no_grad():
+        y = proj(x)
+    out["proj_full_x0"] = x[0, 0].numpy().astype(np.float16)  # frame 0 only: tokens 0..63 depend on it alone
+    out["proj_full_w"] = proj.state_dict()["projector.projector.weight"][:64].numpy().astype(np.float16)
+    out["proj_full_b"] = proj.state_dict()["projector.projector.bias"][:64].numpy()
+    x16 = torch.from_numpy(out["proj_full_x0"].astype(np.float32))
+    w16 = torch.from_numpy(out["proj_full_w"].astype(np.float32))
+    proj2 = nn_utils.AveragePooling3DProjector(768, 64, output_frames=1, output_size=8, mlp_type="linear").eval()
+    with torch.no_grad():
+        proj2.projector.projector.weight.copy_(w16)
+        proj2.projector.projector.bias.copy_(torch.from_numpy(out["proj_full_b"]))
+        out["proj_full_y"] = proj2(x16[None, None]).numpy()
+    # fusion (cross_attention_avg_lq): reduced and near-full embed dims
+    for tag, Ed, llm, T, E, B in (("small", 96, 128, 1024, 4, 2), ("e1", 96, 128, 256, 1, 2), ("wide", 3072, 256, 64, 4, 1)):
+        fus = nn_utils.CrossAttentionAdapterLearnableQuery(embed_dim=Ed, llm_dim=llm, token_length=T,
+                                                           averagetoken=True).eval()
+        with torch.no_grad():
+            fus.attention.in_proj_bias.normal_(0, 0.1)
+            fus.Q.mul_(8.0)  # spread the softmax away from uniform
+        V = [torch.randn(B, T, llm) + 0.2 * e for e in range(E)]
+        with torch.no_grad():
+            y, w = fus(V)
+        sd = fus.state_dict()
+        out[f"fus_{tag}_keys"] = np.array(sorted(sd.keys()))
+        for k in ("Q", "attention.q_proj_weight", "attention.k_proj_weight", "attention.in_proj_bias"):
+            out[f"fus_{tag}_{k}"] = sd[k].numpy()
+        out[f"fus_{tag}_V"] = torch.stack(V, 0).numpy()
+        out[f"fus_{tag}_y"] = y.numpy()
+        out[f"fus_{tag}_w"] = w.numpy()
+    np.savez_compressed(OUT / "projector_fusion.npz", **out)
+    print("projector_fusion: ok", {k: v.shape for k, v in out.items() if k.endswith("_y")})
+
+
+# ----------------------------------------------------------------------------------------------------------
+def _load_languagebind():
+    import transformers.models.clip.modeling_clip as mc
+    if not hasattr(mc, "clip_loss"):
+        mc.clip_loss = lambda similarity: similarity.mean()  # never called on the vision path
+    peft = types.ModuleType("peft")
+    peft.LoraConfig = object
+    peft.get_peft_model = lambda m, c: m
+    sys.modules["peft"] = peft
+    pkg = types.ModuleType("ref_lbvideo")
+    pkg.__path__ = [str(REF / "merv/models/backbones/video/languagebind/video")]
+    sys.modules["ref_lbvideo"] = pkg
+    base = REF / "merv/models/backbones/video/languagebind/video"
+    conf = _load("ref_lbvideo.configuration_video", base / "configuration_video.py", package="ref_lbvideo")
+    mod = _load("ref_lbvideo.modeling_video", base / "modeling_video.py", package="ref_lbvideo")
+    return conf, mod
+
+
+def gen_languagebind():
+    conf, mod = _load_languagebind()
+    out = {}
+    for tag, act in (("gelu", "gelu"), ("quick", "quick_gelu")):
+        torch.manual_seed(7)
+        cfg = conf.CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                                    image_size=56, patch_size=14, hidden_act=act, layer_norm_eps=1e-5,
+                                    add_time_attn=True, num_frames=8)
+        cfg._attn_implementation = "eager"
+        vt = mod.CLIPVisionTransformer(cfg).eval()
+        with torch.no_grad():
+            for p in vt.parameters():  # spread everything away from the trivial init
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+            pix = torch.randn(2, 3, 16, 56, 56)  # [B, C, T, H, W], T=16 with num_frames=8 => two clips per video
+            o = vt(pix, output_hidden_states=True, return_dict=True)
+        hs = o.hidden_states[-2]  # languagebind/__init__.py:85
+        out[f"{tag}_pix"] = pix.numpy()
+        out[f"{tag}_hs_m2"] = hs.numpy()  # [B, T, 17, 128]
+        for k, v in vt.state_dict().items():
+            out[f"{tag}_sd/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "languagebind.npz", **out)
+    print("languagebind: ok", out["gelu_hs_m2"].shape)
+
+
+def gen_vivit():
+    from transformers import VivitConfig, VivitModel
+    torch.manual_seed(11)
+    cfg = VivitConfig(image_size=64, num_frames=8, tubelet_size=[2, 16, 16], hidden_size=128, num_hidden_layers=2,
+                      num_attention_heads=2, intermediate_size=256)
+    assert cfg.hidden_act == "gelu_fast" and cfg.layer_norm_eps == 1e-6 and cfg.qkv_bias
+    m = VivitModel(cfg, add_pooling_layer=False).eval()
+    out = {}
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        m.embeddings.cls_token.normal_(0, 0.5)
+        m.embeddings.position_embeddings.normal_(0, 0.5)
+        pix = torch.randn(2, 8, 3, 64, 64)
+        y = m(pix).last_hidden_state
+    out["pix"] = pix.numpy()
+    out["last_hidden_state"] = y.numpy()
+    for k, v in m.state_dict().items():
+        out[f"sd/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "vivit.npz", **out)
+    print("vivit: ok", y.shape)
+
+
+def gen_hf_crosscheck():
+    out = {}
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    torch.manual_seed(13)
+    cfg = Dinov2WithRegistersConfig(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, mlp_ratio=2, image_size=56,
+                                    patch_size=14, num_register_tokens=4, layerscale_value=1.0, hidden_act="gelu",
+                                    layer_norm_eps=1e-6, qkv_bias=True)
+    m = Dinov2WithRegistersModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        m.embeddings.cls_token.normal_(0, 0.5)
+        m.embeddings.register_tokens.normal_(0, 0.5)
+        m.embeddings.position_embeddings.normal_(0, 0.5)
+        pix = torch.randn(2, 3, 56, 56)
+        o = m(pix, output_hidden_states=True)
+    out["dino_pix"] = pix.numpy()
+    out["dino_hs"] = torch.stack(o.hidden_states, 0).numpy()  # [L+1, B, 1+4+16, D]
+    for k, v in m.state_dict().items():
+        out[f"dino_sd/{k}"] = v.numpy()
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    cfg = SiglipVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                             image_size=64, patch_size=16, hidden_act="gelu", layer_norm_eps=1e-6)
+    m = SiglipVisionModel(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+        pix = torch.randn(2, 3, 64, 64)
+        o = m(pix, output_hidden_states=True)
+    out["siglip_pix"] = pix.numpy()
+    out["siglip_hs"] = torch.stack(o.hidden_states, 0).numpy()
+    for k, v in m.state_dict().items():
+        if "head" in k:
+            continue
+        out[f"siglip_sd/{k}"] = v.numpy()
+    np.savez_compressed(OUT / "hf_crosscheck.npz", **out)
+    print("hf_crosscheck: ok", out["dino_hs"].shape, out["siglip_hs"].shape)
+
+
+def gen_prompts():
+    base = REF / "merv/models/backbones/llm/prompting"
+    pkg = types.ModuleType("ref_prompting")
+    pkg.__path__ = [str(base)]
+    sys.modules["ref_prompting"] = pkg
+    bp = _load("ref_prompting.base_prompter", base / "base_prompter.py", package="ref_prompting")
+    cases = []
+    for turns in (["What is happening in this video?"], ["Describe the video.", "A cat jumps.", "What colour is it?"]):
+        pb = bp.PurePromptBuilder("merv")
+        seq = []
+        for i, msg in enumerate(turns):
+            role = "human" if i % 2 == 0 else "gpt"
+            ret = pb.add_turn(role, msg)
+            seq.append({"role": role, "message": msg, "wrapped": ret})
+        cases.append({"turns": seq, "prompt": pb.get_prompt(),
+                      "potential": pb.get_potential_prompt("And then?") if len(turns) % 2 == 0 else None})
+    (OUT / "prompts.json").write_text(json.dumps(cases, indent=1))
+    print("prompts: ok", cases[0]["prompt"])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["frames", "projfus", "lb", "vivit", "hf", "prompts"]
+    torch.set_num_threads(8)
+    if "frames" in which:
+        gen_frame_indices()
+    if "projfus" in which:
+        gen_projector_fusion()
+    if "lb" in which:
+        gen_languagebind()
+    if "vivit" in which:
+        gen_vivit()
+    if "hf" in which:
+        gen_hf_crosscheck()
+    if "prompts" in which:
+        gen_prompts()
