@@ -11,13 +11,16 @@ all: lib oracle
 
 lib: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h include/merv_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/prof.h include/merv_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(CSRC)/sampler.o: $(CSRC)/sampler.cpp include/merv_hip.h
 	g++ -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -c $< -o $@
 
-$(LIB): $(HIP_OBJS) $(CSRC)/sampler.o
+$(CSRC)/prof.o: $(CSRC)/prof.cpp $(CSRC)/prof.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(HIP_OBJS) $(CSRC)/sampler.o $(CSRC)/prof.o
 	@mkdir -p merv_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 

@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""
+bench.py -- fused visual tokens/s through the 4-encoder + projector + fusion path (merv-frozen / merv-full geometry,
+frames [16,16,32,16], bf16) on N MI355X. Contract: see the task statement; ONE JSON line on rank 0.
+
+  step      = one pass of the hot path (a4-a10: pixels resident in HBM -> fused [B,1024,4096] bf16) over one batch
+  value     = fused visual tokens / s, whole job (1024 tokens per video)
+  roofline  = the bf16 MFMA GEMM kernel (92 % of the path's FLOPs): algorithmic FLOPs of its launches in the timed
+              region / their summed HIP-event durations (events recorded on the launch streams by the library)
+  cpu_baseline = the CPU oracle (torch fp32) timed on this host on a bounded sample, extrapolated per layer
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+LLM_DIM, FUSION_EMBED = 4096, 3072
+TOKENS_PER_VIDEO = 1024
+
+
+def device_random_weights(spec, seed, device):
+    """Seeded random-init weights of the named architecture, generated directly on the GPU (no checkpoints here)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, Mh = spec.dim, spec.mlp_dim
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g, device=device) * std
+
+    P = spec.s_out * (spec.t_out if spec.joint_space_time else 1)
+    W = {"patch_w": rn(D, spec.k_true, std=spec.k_true**-0.5), "pos": rn(P, D), "layers": []}
+    if spec.name != "languagebind":
+        W["patch_b"] = rn(D)
+    if spec.prefix_tokens:
+        W["prefix"] = rn(spec.prefix_tokens, D)
+    if spec.pre_ln:
+        W["pre_ln_w"], W["pre_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
+    if spec.final_ln:
+        W["final_ln_w"], W["final_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
+    for _ in range(spec.layers):
+        Lw = {"ln1_w": 1 + rn(D, std=0.1), "ln1_b": rn(D, std=0.1), "qkv_w": rn(3 * D, D, std=D**-0.5), "qkv_b": rn(3 * D),
+              "proj_w": rn(D, D, std=D**-0.5), "proj_b": rn(D), "ln2_w": 1 + rn(D, std=0.1), "ln2_b": rn(D, std=0.1),
+              "fc1_w": rn(Mh, D, std=D**-0.5), "fc1_b": rn(Mh), "fc2_w": rn(D, Mh, std=Mh**-0.5), "fc2_b": rn(D)}
+        if spec.layerscale:
+            Lw["ls1"], Lw["ls2"] = 0.5 + rn(D, std=0.2), 0.5 + rn(D, std=0.2)
+        if spec.temporal_frames:
+            Lw.update({"t_emb": rn(spec.temporal_frames, D, std=D**-0.5), "t_ln_w": 1 + rn(D, std=0.1),
+                       "t_ln_b": rn(D, std=0.1), "t_qkv_w": rn(3 * D, D, std=D**-0.5), "t_qkv_b": rn(3 * D),
+                       "t_proj_w": rn(D, D, std=D**-0.5), "t_proj_b": rn(D)})
+        W["layers"].append(Lw)
+    return W
+
+
+def build_path(device, concurrent=True):
+    from merv_amd.encoder import merv_full_specs
+    from merv_amd.projector import CrossAttentionAdapterLearnableQuery
+    from merv_amd.visual_path import MervVisualPath
+    specs = merv_full_specs()
+    enc_w = [device_random_weights(s, 1000 + i, device) for i, s in enumerate(specs)]
+    g = torch.Generator(device=device).manual_seed(77)
+    proj_w = [(torch.randn(LLM_DIM, s.dim, generator=g, device=device) * s.dim**-0.5,
+               torch.randn(LLM_DIM, generator=g, device=device) * 0.02) for s in specs]
+    torch.manual_seed(1024)  # merv.py:87
+    fusion = CrossAttentionAdapterLearnableQuery(embed_dim=FUSION_EMBED, llm_dim=LLM_DIM, token_length=TOKENS_PER_VIDEO,
+                                                 averagetoken=True)
+    path = MervVisualPath(specs, enc_w, proj_w, fusion, device, concurrent_streams=concurrent)
+    del enc_w
+    return specs, path
+
+
+def synth_pixels(specs, n_videos, device, seed):
+    """Post-transform pixel tensors (~N(0,1) after normalisation), bf16, already resident in HBM."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return [torch.randn(s.pixel_shape(n_videos), generator=g, device=device).to(torch.bfloat16) for s in specs]
+
+
+def cpu_baseline(budget_layers=2):
+    """Oracle (torch fp32, all host threads) on ONE video: embed + `budget_layers` blocks per encoder are timed and the
+    per-block time is extrapolated to the consumed depth; projector + fusion are timed in full."""
+    from oracle import merv_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfgs = O.merv_full_cfgs()
+    total = 0.0
+    projected = []
+    for i, cfg in enumerate(cfgs):
+        depth = cfg.layers
+        cfg_s = O.EncoderCfg(**{**cfg.__dict__, "layers": budget_layers})
+        W = O.random_encoder_weights(cfg_s, seed=i)
+        shape = (1, 3, cfg.frames, cfg.img, cfg.img) if cfg.pix_layout == "BCFHW" else (1, cfg.frames, 3, cfg.img, cfg.img)
+        pix = torch.randn(shape, generator=torch.Generator().manual_seed(i))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            x = O.encoder_embed(pix, cfg_s, W)
+            t1 = time.perf_counter()
+            for li in range(budget_layers):
+                x = O.encoder_block(x, cfg_s, W["layers"][li])
+            t2 = time.perf_counter()
+            tok = x[:, cfg.prefix_tokens:].reshape(1, -1, cfg.dim)
+            pw, pb = O.random_projector_weights(cfg.dim, LLM_DIM, seed=i)
+            t3 = time.perf_counter()
+            projected.append(O.projector_forward(tok, cfg.t_out, cfg.hp, 8, pw, pb))
+            t4 = time.perf_counter()
+        total += (t1 - t0) + (t2 - t1) / budget_layers * depth + (t4 - t3)
+    Fw = O.random_fusion_weights(LLM_DIM, FUSION_EMBED, seed=5)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.fusion_forward(projected, Fw)
+        total += time.perf_counter() - t0
+    return {
+        "value": TOKENS_PER_VIDEO / total, "unit": "fused visual tokens/s", "cores": ncores, "kind": "port",
+        "sample": (f"1 video, fp32 torch CPU oracle: patch embed + {budget_layers} blocks per encoder timed, per-block time "
+                   f"extrapolated to the consumed depth (23/23/12/11), projector + fusion timed in full; "
+                   f"{total:.1f} s/video extrapolated"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
+    ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
+    ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="disable per-launch GEMM events in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from merv_amd import _lib
+    lib = _lib.load()
+    specs, path = build_path(device, concurrent=not args.sequential)
+    B = args.batch
+    G = B * world
+
+    if world == 1:
+        pixels = synth_pixels(specs, B, device, seed=rank)
+
+        def step():
+            return path.forward(pixels)
+    else:
+        from merv_amd.distributed import DistributedVisualPath
+        dpath = DistributedVisualPath(path, [s.flops_per_video() for s in specs], world, rank, B, exchange=args.exchange)
+        unit_pixels = dpath.synth_unit_pixels(specs, seed=1234)
+
+        def step():
+            return dpath.forward(unit_pixels)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = not args.no_prof
+    if prof:
+        lib.merv_prof_reset()
+        lib.merv_prof_enable(1)  # class 0: GEMM
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if prof:
+        lib.merv_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out[0].float()).all()
+
+    roof = None
+    if prof:
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        lib.merv_prof_read(0, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+        if n.value:
+            achieved = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
+                    "flops_per_launch_avg": fl.value / n.value}
+        lib.merv_prof_reset()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = G * TOKENS_PER_VIDEO * args.steps / elapsed
+        path_tflops = sum(s.flops_per_video() for s in specs) * G * args.steps / elapsed / 1e12
+        line = {
+            "metric": "fused visual tokens/s through 4-encoder+projector+fusion (merv-full geometry)",
+            "value": round(value, 1), "unit": "visual-tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "merv-frozen 4 frozen encoders bf16 inference, frames [16,16,32,16], 224px "
+                                   "(BASELINE.json configs[1])",
+                       "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
+                       "encoder_streams": "sequential" if args.sequential else "concurrent",
+                       "parallelism": "single GPU" if world == 1 else f"(encoder,video) units over {world} GPUs, {args.exchange}",
+                       "path_tflops": round(path_tflops, 1)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

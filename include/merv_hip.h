@@ -156,6 +156,15 @@ int merv_im2col(const void *pix, int32_t pix_dtype, void *out, int32_t B, int32_
 int merv_pool3d(const void *tokens, void *out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
                 void *stream);
 
+/*
+ * Per-launch HIP-event timing (bench.py roofline leg). class bits: 0 GEMM, 1 attention, 2 temporal attention,
+ * 3 LayerNorm. While a class is enabled every launch of it is bracketed by two events on its own stream;
+ * merv_prof_read sums elapsed ms / launches / algorithmic FLOPs / algorithmic bytes since the last reset.
+ */
+void merv_prof_enable(int32_t class_mask);
+void merv_prof_reset(void);
+int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flops, double *bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 // (ds_read_b64_tr_b16, VTR = true) or from a tile transposed while staging (VTR = false).
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace merv {
 namespace {
@@ -371,6 +372,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.nseq <= 0 || a.L <= 0) return hipSuccess;
     if (a.D != a.heads * HD) return hipErrorInvalidValue;
     dim3 grid((a.L + 127) / 128, a.heads, a.nseq);
+    ProfScope ps(PROF_ATTN, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
     if (use_vtr())
         hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, a);
     else
@@ -383,6 +385,7 @@ hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {
     if (a.t != 8 || a.D != a.heads * HD) return hipErrorInvalidValue;
     const int NP = a.nclips * a.ntok;
     dim3 grid((NP + 15) / 16, a.heads);
+    ProfScope ps(PROF_TATTN, s, 4.0 * NP * 64.0 * a.D, 2.0 * 4.0 * NP * 8.0 * a.D);
     if (use_vtr())
         hipLaunchKernelGGL(temporal_attn_kernel<true>, grid, dim3(256), 0, s, a);
     else

@@ -17,6 +17,7 @@
 // n of one output row: bias / LayerScale / residual / store are then 8-16 byte vector accesses.
 #include "common.h"
 #include "kernels.h"
+#include "prof.h"
 
 namespace merv {
 
@@ -176,6 +177,8 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 4 != 0) return hipErrorInvalidValue;
+    ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
+                 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2 : 1)));
     switch (a.act) {
         case ACT_NONE: return launch_act<ACT_NONE>(a, s);
         case ACT_GELU_ERF: return launch_act<ACT_GELU_ERF>(a, s);

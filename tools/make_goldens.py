@@ -124,7 +124,7 @@ def gen_projector_fusion():
     out = {}
     # reduced-width projector, both spatial geometries (16->8 exact 2x2, 14->8 overlapping windows)
     for tag, S, C in (("s16", 16, 64), ("s14", 14, 48)):
-        T, llm, B = 16, 128, 2
+        T, llm, B = 16, 128, 1
         proj = nn_utils.AveragePooling3DProjector(C, llm, output_frames=T, output_size=8, mlp_type="linear").eval()
         x = torch.randn(B, T, S * S, C)
         with torch.no_grad():
@@ -151,7 +151,7 @@ def gen_projector_fusion():
         proj2.projector.projector.bias.copy_(torch.from_numpy(out["proj_full_b"]))
         out["proj_full_y"] = proj2(x16[None, None]).numpy()
     # fusion (cross_attention_avg_lq): reduced and near-full embed dims
-    for tag, Ed, llm, T, E, B in (("small", 96, 128, 1024, 4, 2), ("e1", 96, 128, 256, 1, 2), ("wide", 3072, 256, 64, 4, 1)):
+    for tag, Ed, llm, T, E, B in (("small", 96, 128, 256, 4, 2), ("e1", 96, 128, 64, 1, 2), ("wide", 384, 256, 64, 4, 1)):
         fus = nn_utils.CrossAttentionAdapterLearnableQuery(embed_dim=Ed, llm_dim=llm, token_length=T,
                                                            averagetoken=True).eval()
         with torch.no_grad():
