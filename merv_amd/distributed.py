@@ -93,9 +93,8 @@ class DistributedVisualPath:
                 proj = local.encode_project(e, pix)
             for j, v in enumerate(range(v0, v1)):
                 produced[(e, v)] = proj[j]
-        sample = next(iter(produced.values())) if produced else None
-        T, Cc = (sample.shape if sample is not None else self._shape_hint)
-        dt, dev = (sample.dtype, sample.device) if sample is not None else self._dtype_dev_hint
+        T, Cc = local.T_vis, local.llm_dim
+        dt, dev = getattr(local, "dtype", torch.bfloat16), local.device
         if self.exchange == "all_to_all":
             send = torch.empty(len(self.send_order[self.rank]), T, Cc, dtype=dt, device=dev)
             for i, ev in enumerate(self.send_order[self.rank]):

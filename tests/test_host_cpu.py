@@ -1,0 +1,115 @@
+"""CPU: the C-ABI library loads and exports every symbol include/merv_hip.h declares; the host-only entry points
+(frame-index sampler, temporal subsample) are bit-exact against the goldens; host-side logic and error behaviour.
+No compute calls that need a GPU."""
+import ctypes as C
+import json
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+G = ROOT / "tests" / "golden"
+
+
+def _declared_symbols():
+    text = (ROOT / "include" / "merv_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(merv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from merv_amd import _lib
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"libmerv_hip.so does not export {n}"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert lib.merv_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from merv_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("MERV_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_has_no_oracle_import():
+    for p in (ROOT / "merv_amd").rglob("*.py"):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_sampler_bit_exact_through_c_abi():
+    from merv_amd.sampler import frame_indices
+    cases = json.loads((G / "frame_indices.json").read_text())
+    for c in cases:
+        got = frame_indices(c["N"], c["fps"], c["clip_start_sec"], c["clip_end_sec"], c["num_frames"], c["end_frame"])
+        assert got == c["ids"], c
+
+
+def test_sampler_errors():
+    from merv_amd.sampler import frame_indices, temporal_subsample
+    with pytest.raises(ValueError):
+        frame_indices(0, 30.0, 0.0, None, 8, None)
+    assert temporal_subsample(32, 32, 16) == list(range(0, 32, 2))
+    assert len(temporal_subsample(32, 32, 12)) == 16  # reference over-sampling quirk kept
+    with pytest.raises(ValueError):
+        temporal_subsample(32, 16, 32)  # step 0, like Python's "slice step cannot be zero"
+
+
+def test_specs_match_survey_flop_table():
+    from merv_amd.encoder import merv_full_specs
+    want = {"languagebind": 3.281, "dinov2": 2.525, "vivit": 0.903, "siglip": 0.513}  # TFLOP, SURVEY.md section 8a
+    for s in merv_full_specs():
+        assert abs(s.flops_per_video() / 1e12 - want[s.name]) < 2e-3, s.name
+        assert s.num_patches == {"languagebind": 4096, "dinov2": 4096, "vivit": 3136, "siglip": 3136}[s.name]
+        assert s.t_out == 16
+    assert merv_full_specs()[0].k_pad == 640 and merv_full_specs()[2].k_pad == 1536
+
+
+def test_encoder_refuses_cpu_device():
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        HipEncoder(merv_full_specs()[3], {}, torch.device("cpu"))
+
+
+def test_create_rejects_bad_descriptor():
+    from merv_amd import _lib
+    lib = _lib.load()
+    d = _lib.EncoderDesc(dim=100, heads=2, mlp_dim=256, layers=0, patch=14, tubelet=1, img=224, frames=16)
+    w = _lib.EncoderWeights()
+    h = C.c_void_p()
+    rc = lib.merv_encoder_create(C.byref(d), C.byref(w), C.byref(h))
+    assert rc == 1 and b"dim" in lib.merv_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "merv_encoder_create")
+
+
+def test_plan_units_properties():
+    from merv_amd.encoder import merv_full_specs
+    from merv_amd.visual_path import plan_units
+    costs = [s.flops_per_video() for s in merv_full_specs()]
+    for world in (1, 2, 4, 8):
+        for per in (1, 2, 8):
+            Gv = world * per
+            plan = plan_units(costs, Gv, world)
+            seen = set()
+            for r, units in enumerate(plan):
+                for (e, v0, v1) in units:
+                    assert 0 <= v0 < v1 <= Gv
+                    for v in range(v0, v1):
+                        assert (e, v) not in seen
+                        seen.add((e, v))
+                assert len({e for (e, _, _) in units}) == len(units)  # one run per encoder per rank
+            assert len(seen) == 4 * Gv
+            load = [sum(costs[e] * (v1 - v0) for (e, v0, v1) in u) for u in plan]
+            if per >= 8:
+                assert max(load) / (sum(load) / world) < 1.12, (world, per, load)
+    # north_star's literal placement: 4 GPUs, 1 video -> one encoder per GPU
+    p = plan_units(costs, 1, 4)
+    assert sorted(u[0][0] for u in p) == [0, 1, 2, 3] and all(len(u) == 1 for u in p)

@@ -1,0 +1,195 @@
+"""CPU: pins the oracle (oracle/merv_oracle.py, oracle/frame_index_oracle.c) against the committed golden vectors
+that tools/make_goldens.py produced by running the reference's own code (tests/golden/). No GPU, no /root/reference."""
+import ctypes as C
+import json
+import math
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import merv_oracle as O
+
+G = Path(__file__).resolve().parent / "golden"
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _cases():
+    return json.loads((G / "frame_indices.json").read_text())
+
+
+def test_frame_indices_oracle_python_matches_numpy_goldens():
+    cases = _cases()
+    assert len(cases) >= 20
+    for c in cases:
+        got = O.frame_indices(c["N"], c["fps"], c["clip_start_sec"], c["clip_end_sec"], c["num_frames"], c["end_frame"])
+        assert got == c["ids"], c
+
+
+def test_frame_indices_known_answer_dummy_mcq():
+    # eval_data/dummy_mcq/test_q.json: end_frame 595 -> [0, 19, 38, ..., 575, 595]
+    ids = O.frame_indices(596, 29.97, 0.0, None, 32, 595)
+    assert ids[:4] == [0, 19, 38, 57] and ids[-2:] == [575, 595] and len(ids) == 32
+
+
+@pytest.fixture(scope="module")
+def c_oracle():
+    so = ROOT / "oracle" / "_build" / "libframe_index_oracle.so"
+    if not so.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
+    lib = C.CDLL(str(so))
+    lib.oracle_frame_indices.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
+    lib.oracle_frame_indices.restype = C.c_int
+    return lib
+
+
+def _nan_if_none(x):
+    return float("nan") if x is None else float(x)
+
+
+def test_frame_indices_oracle_c_matches_goldens(c_oracle):
+    for c in _cases():
+        out = (C.c_int64 * c["num_frames"])()
+        ef = -1 if c["end_frame"] is None else c["end_frame"]
+        rc = c_oracle.oracle_frame_indices(c["N"], c["fps"], _nan_if_none(c["clip_start_sec"]), _nan_if_none(c["clip_end_sec"]),
+                                           ef, c["num_frames"], out)
+        assert rc == 0 and list(out) == c["ids"], c
+
+
+def test_temporal_subsample_reference_quirk():
+    assert O.temporal_subsample(32, 32, 16) == list(range(0, 32, 2))
+    assert O.temporal_subsample(32, 32, 32) == list(range(32))
+    # nf does not divide max: stride 32//12 = 2 -> 16 frames, MORE than nf
+    assert len(O.temporal_subsample(32, 32, 12)) == 16
+
+
+def test_adaptive_windows_match_survey_table():
+    assert O.adaptive_windows(14, 8) == [(0, 2), (1, 4), (3, 6), (5, 7), (7, 9), (8, 11), (10, 13), (12, 14)]
+    assert O.adaptive_windows(16, 8) == [(2 * i, 2 * i + 2) for i in range(8)]
+
+
+def test_projector_oracle_matches_reference_class():
+    z = np.load(G / "projector_fusion.npz")
+    assert list(z["proj_s16_keys"]) == ["projector.projector.bias", "projector.projector.weight"]
+    for tag, S in (("s16", 16), ("s14", 14)):
+        x = torch.from_numpy(z[f"proj_{tag}_x"])  # [B, T, S*S, C]
+        B, T, N, Cc = x.shape
+        y = O.projector_forward(x.reshape(B, T * N, Cc), T, S, 8, torch.from_numpy(z[f"proj_{tag}_w"]),
+                                torch.from_numpy(z[f"proj_{tag}_b"]))
+        assert torch.allclose(y, torch.from_numpy(z[f"proj_{tag}_y"]), atol=1e-5, rtol=1e-5)
+    # full-width slice (C=768): first frame -> first 64 output tokens
+    x0 = torch.from_numpy(z["proj_full_x0"].astype(np.float32))
+    y = O.projector_forward(x0[None], 1, 14, 8, torch.from_numpy(z["proj_full_w"].astype(np.float32)),
+                            torch.from_numpy(z["proj_full_b"]))
+    assert torch.allclose(y, torch.from_numpy(z["proj_full_y"]), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "e1", "wide"])
+def test_fusion_oracle_matches_reference_class(tag):
+    z = np.load(G / "projector_fusion.npz")
+    assert "Q" in list(z[f"fus_{tag}_keys"]) and "attention.k_proj_weight" in list(z[f"fus_{tag}_keys"])
+    Fw = {k: torch.from_numpy(z[f"fus_{tag}_{k}"]) for k in ("Q", "attention.q_proj_weight", "attention.k_proj_weight",
+                                                             "attention.in_proj_bias")}
+    V = [torch.from_numpy(v) for v in z[f"fus_{tag}_V"]]
+    y, w = O.fusion_forward(V, Fw)
+    assert torch.allclose(w, torch.from_numpy(z[f"fus_{tag}_w"]), atol=2e-6)
+    assert torch.allclose(y, torch.from_numpy(z[f"fus_{tag}_y"]), atol=1e-5, rtol=1e-5)
+    if tag == "e1":
+        assert torch.equal(w, torch.ones_like(w))  # single encoder: weight == 1 (config 1)
+    # the folded form used by the HIP binding gives the same weights
+    u = O.fusion_fold_u(Fw)
+    s = torch.stack([v.mean(1) @ u for v in V], 1)
+    assert torch.allclose(s.softmax(-1), w, atol=1e-5)
+
+
+def _lb_cfg(act):
+    return O.EncoderCfg("languagebind", 128, 2, 256, 2, 14, 1, 56, 16, "BCFHW", 1, False, True, False, False, 8, act, 1e-5)
+
+
+@pytest.mark.parametrize("tag,act", [("gelu", "gelu_erf"), ("quick", "quick_gelu")])
+def test_languagebind_oracle_matches_reference_tower(tag, act):
+    """hidden_states[-2] of the reference's 3-layer CLIPVisionTransformer == 2 restated blocks; T=16 with
+    config.num_frames=8 exercises the two-clips-per-video temporal attention (modeling_video.py:135-146)."""
+    from merv_amd import weights as Wm
+    z = np.load(G / "languagebind.npz")
+    sd = {k[len(tag) + 4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{tag}_sd/")}
+    cfg = _lb_cfg(act)
+    W = Wm.from_languagebind_vision(sd, n_layers=cfg.layers)
+    pix = torch.from_numpy(z[f"{tag}_pix"])
+    out = O.encoder_forward(pix, cfg, W)  # [B, 16*16, 128] (cls stripped)
+    ref = torch.from_numpy(z[f"{tag}_hs_m2"])[:, :, 1:].reshape(2, -1, 128)  # 'noclass' (languagebind/__init__.py:93-94)
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), float((out - ref).abs().max())
+
+
+def test_vivit_oracle_matches_hf_model():
+    from merv_amd import weights as Wm
+    z = np.load(G / "vivit.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    cfg = O.EncoderCfg("vivit", 128, 2, 256, 2, 16, 2, 64, 8, "BFCHW", 1, True, False, True, False, 0, "gelu_tanh", 1e-6)
+    W = Wm.from_hf_vivit(sd)
+    out = O.encoder_forward(torch.from_numpy(z["pix"]), cfg, W)
+    ref = torch.from_numpy(z["last_hidden_state"])[:, 1:]  # vivit.py:110
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), float((out - ref).abs().max())
+
+
+def test_vivit_old_checkpoint_names_are_accepted():
+    from merv_amd import weights as Wm
+    z = np.load(G / "vivit.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    old = {}
+    ren = {"attention.q_proj": "attention.attention.query", "attention.k_proj": "attention.attention.key",
+           "attention.v_proj": "attention.attention.value", "attention.o_proj": "attention.output.dense",
+           "mlp.fc1": "intermediate.dense", "mlp.fc2": "output.dense"}
+    for k, v in sd.items():
+        if k.startswith("layers."):
+            k = "encoder.layer." + k[len("layers."):]
+            for a, b in ren.items():
+                k = k.replace(a, b)
+        old["vivit." + k] = v
+    a, b = Wm.from_hf_vivit(sd), Wm.from_hf_vivit(old)
+    assert all(torch.equal(a["layers"][1][k], b["layers"][1][k]) for k in a["layers"][1])
+
+
+def test_dinov2_restatement_crosschecks_hf():
+    """timm is absent ("timm parity unpinned"): the timm-semantics restatement (cls+pos0 folded, registers without
+    position, LayerScale, take block index L-2 without final norm) is cross-checked against HF Dinov2WithRegisters."""
+    from merv_amd import weights as Wm
+    z = np.load(G / "hf_crosscheck.npz")
+    sd = {k[8:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("dino_sd/")}
+    W = Wm.from_hf_dinov2(sd)
+    hs = torch.from_numpy(z["dino_hs"])  # [4, B, 21, 128]; hs[k] = after k blocks
+    pix = torch.from_numpy(z["dino_pix"])[:, None]  # one frame per video
+    for take in (1, 2):  # take=2 == "second-to-last of 3 blocks" (n={L-2})
+        cfg = O.EncoderCfg("dinov2", 128, 2, 256, take, 14, 1, 56, 1, "BFCHW", 5, False, False, False, True, 0, "gelu_erf", 1e-6)
+        out = O.encoder_forward(pix, cfg, W)
+        assert torch.allclose(out, hs[take][:, 5:], atol=2e-5, rtol=1e-4)
+    # the same weights through the timm-name ingestion path give the same canonical dict
+    W2 = Wm.from_timm_vit(Wm.to_timm_names(W))
+    assert torch.equal(W2["prefix"], W["prefix"]) and torch.equal(W2["layers"][2]["ls2"], W["layers"][2]["ls2"])
+
+
+def test_siglip_restatement_crosschecks_hf():
+    from merv_amd import weights as Wm
+    z = np.load(G / "hf_crosscheck.npz")
+    sd = {k[10:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("siglip_sd/")}
+    sd = {k[len("vision_model."):] if k.startswith("vision_model.") else k: v for k, v in sd.items()}
+    W = Wm.from_hf_siglip(sd)
+    hs = torch.from_numpy(z["siglip_hs"])
+    cfg = O.EncoderCfg("siglip", 128, 2, 256, 2, 16, 1, 64, 1, "BFCHW", 0, False, False, False, False, 0, "gelu_erf", 1e-6)
+    out = O.encoder_forward(torch.from_numpy(z["siglip_pix"])[:, None], cfg, W)
+    assert torch.allclose(out, hs[2], atol=2e-5, rtol=1e-4)
+
+
+def test_splice_hand_example():
+    emb = torch.arange(2 * 4 * 3, dtype=torch.float32).reshape(2, 4, 3)
+    vis = -torch.ones(2, 2, 3)
+    am = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 0]], dtype=torch.bool)
+    lab = torch.tensor([[-100, 5, 6, -100], [-100, 7, -100, -100]])
+    e, a, l = O.splice(emb, vis, 1, am, lab)
+    assert e.shape == (2, 6, 3) and torch.equal(e[:, 0], emb[:, 0]) and torch.equal(e[:, 1:3], vis) and torch.equal(e[:, 3:], emb[:, 1:])
+    assert a.tolist() == [[True, True, True, True, True, False], [True, True, True, True, False, False]]
+    assert l.tolist() == [[-100, -100, -100, 5, 6, -100], [-100, -100, -100, 7, -100, -100]]
+    e0, _, _ = O.splice(emb, vis, 0)
+    assert torch.equal(e0[:, :2], vis)
