@@ -156,6 +156,9 @@ int merv_im2col(const void *pix, int32_t pix_dtype, void *out, int32_t B, int32_
 int merv_pool3d(const void *tokens, void *out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
                 void *stream);
 
+/* Tuning / test hook: force the GEMM tile configuration (0 auto, 1: 128x128, 2: 256x256, 3: 256x128). */
+void merv_debug_set_gemm_variant(int32_t variant);
+
 /*
  * Per-launch HIP-event timing (bench.py roofline leg). class bits: 0 GEMM, 1 attention, 2 temporal attention,
  * 3 LayerNorm. While a class is enabled every launch of it is bracketed by two events on its own stream;

@@ -281,6 +281,9 @@ extern "C" int merv_splice_forward(const void* emb, const void* vis, int32_t bat
     return 0;
 }
 
+// Tuning / test hook: force a GEMM tile configuration (0 = automatic choice).
+extern "C" void merv_debug_set_gemm_variant(int32_t v) { set_gemm_variant(v); }
+
 // ---- single-kernel wrappers ----
 extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* lscale,
                               const void* res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,

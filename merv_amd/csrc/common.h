@@ -33,8 +33,20 @@ enum : int { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_QUICK_GELU =
 template <int ACT>
 MERV_DEVICE float activate(float x) {
     if constexpr (ACT == ACT_GELU_ERF) {
-        // timm nn.GELU (exact erf form)
-        return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        // timm nn.GELU (exact erf form): 0.5 x (1 + erf(x / sqrt 2)). erfc(|z|) by Abramowitz-Stegun 7.1.26
+        // (|abs err| <= 1.5e-7, far below the bf16 output rounding); 1 + erf(z) = 2 - erfc(z) for z >= 0 and
+        // erfc(-z) for z < 0, so the negative tail keeps its relative accuracy. One v_rcp + one v_exp + 6 FMAs.
+        const float z = x * 0.70710678118654752440f;
+        const float az = fabsf(z);
+        const float t = __frcp_rn(1.0f + 0.3275911f * az);
+        float poly = 1.061405429f;
+        poly = poly * t - 1.453152027f;
+        poly = poly * t + 1.421413741f;
+        poly = poly * t - 0.284496736f;
+        poly = poly * t + 0.254829592f;
+        const float e = poly * t * __expf(-az * az);  // erfc(|z|)
+        const float one_plus_erf = z >= 0.f ? 2.0f - e : e;
+        return 0.5f * x * one_plus_erf;
     } else if constexpr (ACT == ACT_GELU_TANH) {
         // HF "gelu_fast": 0.5x(1+tanh(0.7978845608 x (1+0.044715 x^2)))
         float u = 0.7978845608f * x * (1.0f + 0.044715f * x * x);

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
+#include <math.h>
+#include <type_traits>
 
 namespace merv {
 
@@ -40,44 +42,30 @@ MERV_DEVICE void dma_rows8(const bf16_t* __restrict__ g, int ld, int row0, int r
                                      (__attribute__((address_space(3))) void*)(lds_tile + rowblk * 1024), 16, 0, 0);
 }
 
-template <int ACT>
-MERV_DEVICE void epilogue_store4(const GemmArgs& p, int m, int n, f32x4 v) {
-    if (m >= p.M) return;
-    if (p.bias) {
-        const float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = activate<ACT>(v[i]);
-    if (p.lscale) {
-        const float4 s = *(const float4*)(p.lscale + n);
-        v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-    }
-    if (p.res) {
-        const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-        const u32x2 r = *(const u32x2*)(p.res + (size_t)rr * p.ldres + n);
-        v[0] += bflo(r[0]); v[1] += bfhi(r[0]); v[2] += bflo(r[1]); v[3] += bfhi(r[1]);
-    }
-    int orow = m;
-    if (p.out_group > 0) orow = (m / p.out_group) * p.out_stride + p.out_off + (m % p.out_group);
-    u32x2 o;
-    o[0] = pack2bf(v[0], v[1]);
-    o[1] = pack2bf(v[2], v[3]);
-    *(u32x2*)(p.C + (size_t)orow * p.ldc + n) = o;
+template <int N>
+MERV_DEVICE void wait_dma_barrier() {
+    // my DMAs except the youngest N have landed and my LDS reads have returned; after the barrier that holds for
+    // every wave of the block
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// BM x BN block tile, WAVES_M x WAVES_N waves.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int ACT>
+// BM x BN block tile, WAVES_M x WAVES_N waves, NSTAGE LDS stages (dynamic shared memory), ONE barrier per K-step:
+//   wait(my DMA of tile kt) ; barrier  => tile kt is complete in LDS AND every wave has finished reading tile kt-1
+//   issue DMA of tile kt+NSTAGE-1 into the stage tile kt-1 occupied, one 1-KiB piece after each row of MFMAs
+//   (a DMA piece costs ~60-180 issue cycles: spread out, the SIMD's other wave fills the gap with its MFMAs)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, int ACT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // per-wave output tile
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int DMA_PER_STAGE = (BM / 8 + BN / 8) / NW;  // LDS-DMA instructions per wave per stage
+    constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;
+    constexpr int DPS = A_PIECES + W_PIECES;  // LDS-DMA instructions per wave per stage
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over waves");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 stages");
 
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -87,7 +75,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / BN;
     const int nwg = tilesM * tilesN;
     const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GM = 8;
+    constexpr int GM = (BM >= 256) ? 4 : 8;
     const int per_group = GM * tilesN;
     const int grp = id / per_group;
     const int first_m = grp * GM;
@@ -97,15 +85,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     const int tn = in_grp / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    auto stage = [&](int kt, int buf) {
+    // piece `pc` (0..DPS-1) of tile kt into stage `buf`
+    auto dma_piece = [&](int kt, int buf, int pc) {
         char* a_tile = smem + buf * STAGE_BYTES;
-        char* w_tile = a_tile + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < BM / 8 / NW; ++i)
-            dma_rows8(p.A, p.lda, m0, p.M - 1, i * NW + wave, kt * BK, a_tile, lane);
-#pragma unroll
-        for (int i = 0; i < BN / 8 / NW; ++i)
-            dma_rows8(p.W, p.ldw, n0, p.N - 1, i * NW + wave, kt * BK, w_tile, lane);
+        if (pc < A_PIECES) dma_rows8(p.A, p.lda, m0, p.M - 1, pc * NW + wave, kt * BK, a_tile, lane);
+        else dma_rows8(p.W, p.ldw, n0, p.N - 1, (pc - A_PIECES) * NW + wave, kt * BK, a_tile + A_BYTES, lane);
     };
 
     f32x4 acc[NI][MI];
@@ -120,16 +104,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     const int fq = lane >> 4;
     const int sw = lane & 7;  // == row & 7 for every fragment row this lane reads (fragment bases are multiples of 16)
 
-    stage(0, 0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) {
-            stage(kt + 1, buf ^ 1);
-            // all but the youngest DMA_PER_STAGE DMAs (tile kt+1) have landed => tile kt is in LDS
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(DMA_PER_STAGE) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nkt) {
+#pragma unroll
+            for (int pc = 0; pc < DPS; ++pc) dma_piece(s0, s0, pc);
         }
+
+    // one K-step; PREFETCH is a compile-time flag so the steady-state body is one straight-line scheduling region
+    auto k_step = [&](int kt, int buf, auto prefetch_tag) {
+        constexpr bool PREFETCH = decltype(prefetch_tag)::value;
+        const int kt_next = kt + NSTAGE - 1;
+        int buf_next = buf + NSTAGE - 1;
+        if (buf_next >= NSTAGE) buf_next -= NSTAGE;
         const char* a_tile = smem + buf * STAGE_BYTES + (wr * WTM + frow) * ROW_BYTES;
         const char* w_tile = smem + buf * STAGE_BYTES + A_BYTES + (wc * WTN + frow) * ROW_BYTES;
 #pragma unroll
@@ -141,42 +128,138 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
 #pragma unroll
             for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8*)(w_tile + i * 16 * ROW_BYTES + coff);
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                if constexpr (PREFETCH) {
+                    // DMA pieces of the prefetched tile, spread over the (BK/32)*NI MFMA rows of this K-step
+                    constexpr int ROWS = (BK / 32) * NI;
+                    const int r = kk * NI + i;
+#pragma unroll
+                    for (int pc = 0; pc < DPS; ++pc)
+                        if (pc * ROWS / DPS == r) dma_piece(kt_next, buf_next, pc);
+                }
+            }
         }
-        // every wave's LDS reads of this stage are complete before the next iteration's DMA may overwrite it
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    int buf = 0;
+    int kt = 0;
+    // steady state: NSTAGE-1 tiles in flight, the oldest of them is needed now
+    for (; kt + NSTAGE - 1 < nkt; ++kt) {
+        wait_dma_barrier<(NSTAGE - 2) * DPS>();
+        k_step(kt, buf, std::true_type{});
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    }
+    // drain: no more prefetches; `left` tiles (this one included) are still to be multiplied
+    for (; kt < nkt; ++kt) {
+        const int left = nkt - kt;  // 1 .. NSTAGE-1
+        if (left >= 3) wait_dma_barrier<2 * DPS>();
+        else if (left == 2) wait_dma_barrier<DPS>();
+        else wait_dma_barrier<0>();
+        k_step(kt, buf, std::false_type{});
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
 
     // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 fragment ----
+    // All loads (bias / LayerScale per n-fragment, residual per fragment) are issued BEFORE the first store: C may
+    // alias the residual (in-place x += ...), so a load placed after a store could not be hoisted by the compiler
+    // and every fragment would pay a full memory round trip.
+    float4 bias4[NI], ls4[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wc * WTN + i * 16 + fq * 4;
+        bias4[i] = p.bias ? *(const float4*)(p.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+        ls4[i] = p.lscale ? *(const float4*)(p.lscale + n) : float4{1.f, 1.f, 1.f, 1.f};
+    }
+    size_t c_off[MI];
+    bool valid[MI];
+    u32x2 resv[NI][MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+        const int m = m0 + wr * WTM + j * 16 + frow;
+        valid[j] = m < p.M;
+        int orow = m;
+        if (p.out_group > 0) orow = (m / p.out_group) * p.out_stride + p.out_off + (m % p.out_group);
+        c_off[j] = (size_t)orow * p.ldc;
+        if (p.res) {
+            const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+            const bf16_t* rrow = p.res + (size_t)rr * p.ldres + n0 + wc * WTN + fq * 4;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) resv[i][j] = valid[j] ? *(const u32x2*)(rrow + i * 16) : u32x2{0u, 0u};
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) resv[i][j] = u32x2{0u, 0u};
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wc * WTN + i * 16 + fq * 4;
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
-            const int n = n0 + wc * WTN + i * 16 + fq * 4;
-            const int m = m0 + wr * WTM + j * 16 + frow;
-            epilogue_store4<ACT>(p, m, n, acc[i][j]);
+            f32x4 v = acc[i][j];
+            v[0] = activate<ACT>(v[0] + bias4[i].x) * ls4[i].x + bflo(resv[i][j][0]);
+            v[1] = activate<ACT>(v[1] + bias4[i].y) * ls4[i].y + bfhi(resv[i][j][0]);
+            v[2] = activate<ACT>(v[2] + bias4[i].z) * ls4[i].z + bflo(resv[i][j][1]);
+            v[3] = activate<ACT>(v[3] + bias4[i].w) * ls4[i].w + bfhi(resv[i][j][1]);
+            u32x2 o;
+            o[0] = pack2bf(v[0], v[1]);
+            o[1] = pack2bf(v[2], v[3]);
+            if (valid[j]) *(u32x2*)(p.C + c_off[j] + n) = o;
         }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT>
+hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = NSTAGE * (BM + BN) * ROW_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, ACT>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = a.N / BN;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(WM * WN * 64), LDS, s, a);
+    return hipGetLastError();
+}
+
+int g_gemm_variant = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
+
+// Tile choice (measured on MI355X, tools/gemm_bench.py): the 256x128 tile with a 3-deep LDS ring is the fastest
+// configuration whenever it yields enough blocks to occupy the chip; small launches use 128x128 tiles, two blocks per
+// CU. The 256x256 tile has the best bytes/FLOP but pays the longest per-tile prologue + epilogue (one block per CU).
+int choose_variant(const GemmArgs& a) {
+    if (g_gemm_variant) return g_gemm_variant;
+    const long tiles3 = (long)((a.M + 255) / 256) * (a.N / 128);
+    return tiles3 >= 200 ? 3 : 1;
 }
 
 template <int ACT>
 hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
-    constexpr int BM = 128, BN = 128;
-    const int tilesM = (a.M + BM - 1) / BM, tilesN = a.N / BN;
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 2, 2, ACT>), dim3(tilesM * tilesN), dim3(256), 0, s, a);
-    return hipGetLastError();
+    switch (choose_variant(a)) {
+        case 2: return launch_cfg<256, 256, 2, 4, 2, ACT>(a, s);
+        case 3: return launch_cfg<256, 128, 4, 2, 3, ACT>(a, s);
+        case 4: return launch_cfg<128, 128, 2, 2, 3, ACT>(a, s);
+        case 5: return launch_cfg<128, 128, 2, 2, 4, ACT>(a, s);
+        default: return launch_cfg<128, 128, 2, 2, 2, ACT>(a, s);
+    }
 }
 
 }  // namespace
 
-// Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc/ldres % 8 == 0.
+void set_gemm_variant(int v) { g_gemm_variant = v; }
+
+// Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc % 8 == 0.
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 4 != 0) return hipErrorInvalidValue;
+    if (g_gemm_variant == 2 && a.N % 256 != 0) return hipErrorInvalidValue;
     ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
                  2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2 : 1)));
     switch (a.act) {

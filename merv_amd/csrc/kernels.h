@@ -20,6 +20,7 @@ struct GemmArgs {
     int act;          // ACT_*
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+void set_gemm_variant(int v);  // 0 auto, 1: 128x128 tile, 2: 256x256, 3: 256x128 (tuning / tests)
 
 // Row LayerNorm (fp32 statistics), optional fused "x += add[(row / add_div) % add_mod]" written back in place
 // (LanguageBind temporal embedding, modeling_video.py:138-141).
