@@ -1,0 +1,31 @@
+"""GPU: every GEMM tile configuration (forced through merv_debug_set_gemm_variant) against torch fp32, incl. ragged M,
+many tiles per persistent block, fused epilogues and in-place residual."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 9])
+@pytest.mark.parametrize("M,N,K", [(1, 256, 64), (300, 256, 128), (4112, 1024, 1024), (33000, 768, 192), (70000, 256, 64)])
+def test_variant(dev, variant, M, N, K):
+    from merv_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + variant)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ls = (0.5 + torch.rand(N, generator=g)).to(dev)
+    x = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    ref = x.float() + ls * F.gelu(a.float() @ w.float().t() + bias)
+    lib.merv_debug_set_gemm_variant(variant)
+    try:
+        ops.gemm(a, w, bias=bias, act="gelu_erf", lscale=ls, res=x, out=x)  # in place
+        plain = ops.gemm(a, w)
+    finally:
+        lib.merv_debug_set_gemm_variant(0)
+    assert rel_l2(x, ref) < 6e-3, (variant, M, N, K)
+    assert rel_l2(plain, a.float() @ w.float().t()) < 6e-3
