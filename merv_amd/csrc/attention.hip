@@ -21,6 +21,9 @@ namespace merv {
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+// raw v_exp_f32 (2^x): exp2f() adds range scaling (v_cmp + v_cndmask + v_ldexp per call) that softmax does not need --
+// arguments are <= 0 and underflow to 0 is the wanted result; -inf -> 0.
+MERV_DEVICE float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 constexpr int HD = 64;               // head_dim
 constexpr int KROW = 128;            // bytes per K row in LDS
 constexpr int VROW_TR = 192;         // bytes per V row (row-major image for transposed reads; 192 keeps 4 rows on disjoint banks)
@@ -78,11 +81,19 @@ MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u3
     }
 }
 
-template <bool VTR>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+// NW waves per block, each wave owns QPW consecutive 32-row query tiles: one block covers NW*QPW*32 queries of one
+// (sequence, head) and streams the K/V tiles ONCE for all of them (L = 257/261 -> 3 waves x 3 tiles = 288 rows, one
+// block per (sequence, head); L = 196 -> 4 x 2; L = 3137 -> 13 blocks of 4 x 2).
+template <bool VTR, int NW, int QPW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
+    constexpr int NT = NW * 64;
     constexpr int V_BYTES = VTR ? 64 * VROW_TR : 64 * VT_ROW;
     constexpr int VROWB = VTR ? VROW_TR : VT_ROW;
-    __shared__ __attribute__((aligned(16))) char smem[64 * KROW + V_BYTES];
+    constexpr int KSTG = (512 + NT - 1) / NT;   // 16-byte chunks of a 64x64 bf16 tile per thread
+    constexpr int PSTG = (256 + NT - 1) / NT;   // (key pair, chunk) items per thread for the transposing V path
+    constexpr int OUT_BYTES = NW * 32 * 128;    // output staging (reuses the K/V region after the last tile)
+    constexpr int LDS_BYTES = (64 * KROW + V_BYTES) > OUT_BYTES ? (64 * KROW + V_BYTES) : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* k_lds = smem;
     char* v_lds = smem + 64 * KROW;
 
@@ -97,64 +108,75 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
     const bf16_t* kbase = base + D + head * HD;
     const bf16_t* vbase = base + 2 * D + head * HD;
 
-    const int q_row = blockIdx.x * 128 + wave * 32 + r;
-    const int q_ld = q_row < L ? q_row : L - 1;
+    const int q_base = (blockIdx.x * NW + wave) * (QPW * 32);  // first query row of this wave
 
     // Q^T B-operand fragments: element j of step s = Q[q][16 s + 8 h + j]
-    bf16x8 qf[4];
+    bf16x8 qf[QPW][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int q_row = q_base + qi * 32 + r;
+        const int q_ld = q_row < L ? q_row : L - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[qi][s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+    }
 
-    f32x16 oacc[2];
+    f32x16 oacc[QPW][2];
+    float m_run[QPW], l_run[QPW];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int qi = 0; qi < QPW; ++qi) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { oacc[qi][0][i] = 0.f; oacc[qi][1][i] = 0.f; }
+        m_run[qi] = -INFINITY;
+        l_run[qi] = 0.f;
+    }
     const float sc = p.scale * LOG2E;
 
     // staging registers (issue global loads early, write LDS after the barrier)
-    u32x4 kreg[2], vreg[2];
+    u32x4 kreg[KSTG], vreg[VTR ? KSTG : 2 * PSTG];
     auto load_tile = [&](int kv0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            int key = kv0 + (idx >> 3);
-            key = key < L ? key : L - 1;
-            kreg[i] = *(const u32x4*)(kbase + (size_t)key * ld + (idx & 7) * 8);
-        }
-        if constexpr (VTR) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;
+        for (int i = 0; i < KSTG; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < 512) {
                 int key = kv0 + (idx >> 3);
                 key = key < L ? key : L - 1;
-                vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + (idx & 7) * 8);
+                kreg[i] = *(const u32x4*)(kbase + (size_t)key * ld + (idx & 7) * 8);
+                if constexpr (VTR) vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + (idx & 7) * 8);
             }
-        } else {
-            const int kp = tid >> 3, c = tid & 7;
+        }
+        if constexpr (!VTR) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int key = kv0 + 2 * kp + i;
-                key = key < L ? key : L - 1;
-                vreg[i] = *(const u32x4*)(vbase + (size_t)key * ld + c * 8);
+            for (int i = 0; i < PSTG; ++i) {
+                const int pidx = tid + NT * i;
+                if (pidx < 256) {
+                    const int kp = pidx >> 3, c = pidx & 7;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        int key = kv0 + 2 * kp + u;
+                        key = key < L ? key : L - 1;
+                        vreg[2 * i + u] = *(const u32x4*)(vbase + (size_t)key * ld + c * 8);
+                    }
+                }
             }
         }
     };
     auto write_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int key = idx >> 3, c = idx & 7;
-            *(u32x4*)(k_lds + key * KROW + ((c ^ kswz(key)) * 16)) = kreg[i];
-        }
-        if constexpr (VTR) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;
-                *(u32x4*)(v_lds + (idx >> 3) * VROW_TR + (idx & 7) * 16) = vreg[i];
+        for (int i = 0; i < KSTG; ++i) {
+            const int idx = tid + NT * i;
+            if (idx < 512) {
+                const int key = idx >> 3, c = idx & 7;
+                *(u32x4*)(k_lds + key * KROW + ((c ^ kswz(key)) * 16)) = kreg[i];
+                if constexpr (VTR) *(u32x4*)(v_lds + key * VROW_TR + c * 16) = vreg[i];
             }
-        } else {
-            write_vt_pair(v_lds, VT_ROW, tid >> 3, tid & 7, vreg[0], vreg[1]);
+        }
+        if constexpr (!VTR) {
+#pragma unroll
+            for (int i = 0; i < PSTG; ++i) {
+                const int pidx = tid + NT * i;
+                if (pidx < 256) write_vt_pair(v_lds, VT_ROW, pidx >> 3, pidx & 7, vreg[2 * i], vreg[2 * i + 1]);
+            }
         }
     };
 
@@ -166,82 +188,114 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
         write_tile();
         __syncthreads();
         if (t + 1 < ntiles) load_tile(kv0 + 64);
-
-        // ---- S^T = K Q^T (keys on rows, queries on lanes) ----
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
-            const int key = kb * 32 + r;
-            const char* krow = k_lds + key * KROW;
-            const int sw = kswz(key);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
-            }
-        }
-        // ---- online softmax (this lane: one query, 32 of the tile's 64 keys) ----
         const bool tail = kv0 + 64 > L;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = sacc[kb][i] * sc;
-                if (tail) {
-                    const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (key >= L) v = -INFINITY;
-                }
-                sacc[kb][i] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = exp2f(sacc[kb][i] - m_new);
-                sacc[kb][i] = e;
-                psum += e;
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
 
-        // ---- O^T += V^T P^T ----
+        // ---- S^T = K Q^T (keys on rows, queries on lanes). With <= 2 query tiles per wave all of them are issued
+        //      first, so the MFMAs of tile qi+1 run in the matrix pipe under the softmax VALU work of tile qi; with 3
+        //      tiles the score registers would not fit and each tile is multiplied right before its softmax ----
+        constexpr bool S_FIRST = QPW <= 2;
+        f32x16 sacc[S_FIRST ? QPW : 1][2];
+        auto scores = [&](int qi, f32x16(&sa)[2]) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                const int key = kb * 32 + r;
+                const char* krow = k_lds + key * KROW;
+                const int sw = kswz(key);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pf = pack8(sacc[kb], 8 * s2);
-                const int key_base = kb * 32 + 16 * s2;
+                for (int i = 0; i < 16; ++i) sa[kb][i] = 0.f;
 #pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const bf16x8 vf = load_vt_frag<VTR>(v_lds, key_base, db, lane, VROWB);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
+                    sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][s], sa[kb], 0, 0, 0);
                 }
             }
+        };
+        if constexpr (S_FIRST) {
+#pragma unroll
+            for (int qi = 0; qi < QPW; ++qi) scores(qi, sacc[qi]);
+        }
+#pragma unroll
+        for (int qi = 0; qi < QPW; ++qi) {
+            if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
+            f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
+            if constexpr (!S_FIRST) scores(qi, sa);
+            // ---- online softmax (this lane: one query, 32 of the tile's 64 keys); exponent = fma(s, c, -m c) ----
+            float mx = -INFINITY;
+            if (tail) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= L) sa[kb][i] = -INFINITY;
+                    }
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[kb][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
+            const float m_new = fmaxf(m_run[qi], mx);
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = fast_exp2(fmaf(sa[kb][i], sc, -m_new));
+                    sa[kb][i] = e;
+                    psum += e;
+                }
+            if (!__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
+                const float alpha = fast_exp2(m_run[qi] - m_new);
+                l_run[qi] *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { oacc[qi][0][i] *= alpha; oacc[qi][1][i] *= alpha; }
+                m_run[qi] = m_new;
+            }
+            l_run[qi] += psum;
+
+            // ---- O^T += V^T P^T ----
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pf = pack8(sa[kb], 8 * s2);
+                    const int key_base = kb * 32 + 16 * s2;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 vf = load_vt_frag<VTR>(v_lds, key_base, db, lane, VROWB);
+                        oacc[qi][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qi][db], 0, 0, 0);
+                    }
+                }
+        }
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row < L) {
-        bf16_t* orow = p.out + ((size_t)seq * L + q_row) * D + head * HD;
+    // ---- output: transpose each 32 x 64 tile through LDS so the global stores are 16 B per lane, 128 B per row ----
+    __syncthreads();  // every wave is done with the K/V tiles
+    char* stg = smem + wave * (32 * 128);
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi) {
+        const int q0 = q_base + qi * 32;
+        if (q0 >= L) continue;
+        const float l_tot = l_run[qi] + __shfl_xor(l_run[qi], 32, 64);
+        const float inv = 1.0f / l_tot;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 u32x2 o;
-                o[0] = pack2bf(oacc[db][4 * i + 0] * inv, oacc[db][4 * i + 1] * inv);
-                o[1] = pack2bf(oacc[db][4 * i + 2] * inv, oacc[db][4 * i + 3] * inv);
-                *(u32x2*)(orow + db * 32 + 8 * i + 4 * h) = o;
+                o[0] = pack2bf(oacc[qi][db][4 * i + 0] * inv, oacc[qi][db][4 * i + 1] * inv);
+                o[1] = pack2bf(oacc[qi][db][4 * i + 2] * inv, oacc[qi][db][4 * i + 3] * inv);
+                *(u32x2*)(stg + r * 128 + (((db * 4 + i) ^ (r & 7)) * 16) + 8 * h) = o;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: in-wave ordering suffices
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = (lane >> 3) + 8 * it, c = lane & 7;
+            const u32x4 v = *(const u32x4*)(stg + rr * 128 + ((c ^ (rr & 7)) * 16));
+            if (q0 + rr < L) *(u32x4*)(p.out + ((size_t)seq * L + q0 + rr) * D + head * HD + c * 8) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads returned before the next tile overwrites
     }
 }
 
@@ -323,7 +377,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalAttnArgs p) 
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float e = exp2f(sacc[i] - mx);
+        const float e = fast_exp2(sacc[i] - mx);
         sacc[i] = e;
         psum += e;
     }
@@ -368,16 +422,27 @@ static bool use_vtr() {
     return !(e && e[0] == '0');
 }
 
+template <int NW, int QPW>
+static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
+    const int rows = NW * QPW * 32;
+    dim3 grid((a.L + rows - 1) / rows, a.heads, a.nseq);
+    if (use_vtr())
+        hipLaunchKernelGGL((attn_kernel<true, NW, QPW>), grid, dim3(NW * 64), 0, s, a);
+    else
+        hipLaunchKernelGGL((attn_kernel<false, NW, QPW>), grid, dim3(NW * 64), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.nseq <= 0 || a.L <= 0) return hipSuccess;
     if (a.D != a.heads * HD) return hipErrorInvalidValue;
-    dim3 grid((a.L + 127) / 128, a.heads, a.nseq);
     ProfScope ps(PROF_ATTN, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
-    if (use_vtr())
-        hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(256), 0, s, a);
-    return hipGetLastError();
+    // block shape: least padded query tiles; 257- / 261-token sequences are exactly 9 tiles = 3 waves x 3
+    const int t32 = (a.L + 31) / 32;
+    if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
+    const int pad9 = (t32 + 8) / 9 * 9 - t32, pad8 = (t32 + 7) / 8 * 8 - t32;
+    if (pad9 < pad8) return launch_attn_cfg<3, 3>(a, s);
+    return launch_attn_cfg<4, 2>(a, s);
 }
 
 hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {

@@ -23,7 +23,13 @@ MERV_DEVICE bf16_t f2bf(float x) {
     return __builtin_bit_cast(bf16_t, b);
 }
 MERV_DEVICE float bf2f(bf16_t x) { return __builtin_bit_cast(float, ((uint32_t)x) << 16); }
-MERV_DEVICE uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two f32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN-preserving)
+MERV_DEVICE uint32_t pack2bf(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 MERV_DEVICE float bflo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 MERV_DEVICE float bfhi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
