@@ -5,8 +5,8 @@ frames [16,16,32,16], bf16) on N MI355X. Contract: see the task statement; ONE J
 
   step      = one pass of the hot path (a4-a10: pixels resident in HBM -> fused [B,1024,4096] bf16) over one batch
   value     = fused visual tokens / s, whole job (1024 tokens per video)
-  roofline  = the bf16 MFMA GEMM kernel (92 % of the path's FLOPs): algorithmic FLOPs of its launches in the timed
-              region / their summed HIP-event durations (events recorded on the launch streams by the library)
+  roofline  = the bf16 MFMA GEMM kernel (92 % of the path's FLOPs): algorithmic FLOPs (2MNK) of all its launches in K
+              steps / their summed HIP-event durations (events recorded by the library on the launch stream)
   cpu_baseline = the CPU oracle (torch fp32) timed on this host on a bounded sample, extrapolated per layer
 """
 from __future__ import annotations
@@ -85,11 +85,13 @@ def synth_pixels(specs, n_videos, device, seed):
     return [torch.randn(s.pixel_shape(n_videos), generator=g, device=device).to(torch.bfloat16) for s in specs]
 
 
-def cpu_baseline(budget_layers=2):
-    """Oracle (torch fp32, all host threads) on ONE video: embed + `budget_layers` blocks per encoder are timed and the
-    per-block time is extrapolated to the consumed depth; projector + fusion are timed in full."""
+def cpu_baseline(budget_layers=2, threads=None):
+    """Oracle (torch fp32) on ONE video: embed + `budget_layers` blocks per encoder are timed and the per-block time is
+    extrapolated to the consumed depth; projector + fusion are timed in full. Thread count: torch's intra-op pool
+    degrades badly past ~16 threads on these shapes (measured on the 256-core GPU host: 16 threads 0.118 s, 64 threads
+    0.30 s, 256 threads 6.5 s for the same two SigLIP blocks), so the baseline uses min(cores, 16) and says so."""
     from oracle import merv_oracle as O
-    ncores = os.cpu_count() or 1
+    ncores = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
     cfgs = O.merv_full_cfgs()
     total = 0.0
@@ -119,7 +121,7 @@ def cpu_baseline(budget_layers=2):
         O.fusion_forward(projected, Fw)
         total += time.perf_counter() - t0
     return {
-        "value": TOKENS_PER_VIDEO / total, "unit": "fused visual tokens/s", "cores": ncores, "kind": "port",
+        "value": round(TOKENS_PER_VIDEO / total, 2), "unit": "visual-tokens/s", "cores": ncores, "kind": "port",
         "sample": (f"1 video, fp32 torch CPU oracle: patch embed + {budget_layers} blocks per encoder timed, per-block time "
                    f"extrapolated to the consumed depth (23/23/12/11), projector + fusion timed in full; "
                    f"{total:.1f} s/video extrapolated"),
@@ -135,7 +137,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="disable per-launch GEMM events in the timed region")
+    ap.add_argument("--no-prof", action="store_true", help="skip the roofline leg (per-launch GEMM events, N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,39 +184,59 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    prof = not args.no_prof
-    if prof:
-        lib.merv_prof_reset()
-        lib.merv_prof_enable(1)  # class 0: GEMM
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if prof:
-        lib.merv_prof_enable(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out[0].float()).all()
 
+    # ---- roofline leg: the same K steps again with every GEMM launch bracketed by HIP events on its own stream.
+    # Kernel durations are only well defined when kernels do not overlap, so this pass runs the encoders on ONE
+    # stream (the throughput above is measured with concurrent streams and no events).
     roof = None
-    if prof:
+    if not args.no_prof and world == 1:
+        was = path.concurrent
+        path.concurrent = False
+        step(); torch.cuda.synchronize()
+        lib.merv_prof_reset()
+        lib.merv_prof_enable(1)  # class 0: GEMM
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        lib.merv_prof_enable(0)
+        path.concurrent = was
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         lib.merv_prof_read(0, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
         if n.value:
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            traffic = None
+            tf = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
+            if tf.exists():
+                try:
+                    traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all tile configs, all launches of the step)",
+                    "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
-                    "flops_per_launch_avg": fl.value / n.value}
+                    "flops_per_launch": round(fl.value / n.value / 1e9, 3), "flops_unit": "GFLOP",
+                    "algorithmic_bytes_per_launch": round(by.value / n.value),
+                    "gemm_ms_per_step": round(ms.value / args.steps, 3)}
         lib.merv_prof_reset()
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = G * TOKENS_PER_VIDEO * args.steps / elapsed
-        path_tflops = sum(s.flops_per_video() for s in specs) * G * args.steps / elapsed / 1e12
+        flops_video = sum(s.flops_per_video() + 2.0 * TOKENS_PER_VIDEO * s.dim * LLM_DIM for s in specs)  # + projectors
+        path_tflops = flops_video * G * args.steps / elapsed / 1e12
         line = {
             "metric": "fused visual tokens/s through 4-encoder+projector+fusion (merv-full geometry)",
             "value": round(value, 1), "unit": "visual-tokens/s", "n_gpus": world, "steps": args.steps,
@@ -225,7 +247,8 @@ def main():
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
                        "encoder_streams": "sequential" if args.sequential else "concurrent",
                        "parallelism": "single GPU" if world == 1 else f"(encoder,video) units over {world} GPUs, {args.exchange}",
-                       "path_tflops": round(path_tflops, 1)},
+                       "path_tflops": round(path_tflops, 1), "path_frac_of_mfma_peak": round(path_tflops / PEAK_BF16_TFLOPS, 4),
+                       "flops_per_video_T": round(flops_video / 1e12, 3)},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
