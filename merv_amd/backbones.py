@@ -1,0 +1,225 @@
+"""
+Video backbones with the reference's class names, constructor arguments, properties and registry keys
+(merv/models/backbones/video/*.py, merv/models/materialize.py:31-73,107-129) whose forward() runs the HIP encoder.
+
+Differences from the reference, all forced by this environment (no network, no timm):
+  * weights are not downloaded in __init__; pass `weights=` (an upstream state dict of the matching family or a
+    canonical dict, see merv_amd/weights.py) or `weights="random"` for seeded synthetic parameters;
+  * only the token selections used by merv-full / merv-frozen and the single-encoder configs are wired
+    (`*-noclass`, `*-all-tokens`, `*-all-no-cls-16frames`, `*-all-no-cls`); the other registry keys exist and raise
+    NotImplementedError when constructed;
+  * `video_transform` (CPU PIL / torchvision pipelines) is the next row of the scope table and
+    is not provided here: callers hand over post-transform tensors.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import weights as W
+from .encoder import EncoderSpec, HipEncoder
+
+
+class VideoBackbone(nn.Module):
+    """base_video.py:56-105"""
+
+    def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
+                 num_frames: int = 8) -> None:
+        super().__init__()
+        self.identifier = video_backbone_id
+        self.image_resize_strategy = image_resize_strategy
+        self.default_image_size = default_image_size
+        self.num_frames = num_frames
+        self.featurizer: Optional[HipEncoder] = None
+        self.video_transform = None
+
+    def get_video_transform(self):
+        return self.video_transform
+
+    def get_fsdp_wrapping_policy(self) -> Callable:
+        raise NotImplementedError("encoders are frozen and forward-only on the HIP path (merv.py:315-384)")
+
+    # -- shared plumbing -------------------------------------------------------------------------------------
+    def _build(self, spec: EncoderSpec, weights, device, ingest: Callable) -> None:
+        self.spec = spec
+        if weights is None:
+            raise ValueError(f"{type(self).__name__}: pass weights=<state dict> or weights='random' (no hub access here)")
+        if isinstance(weights, str) and weights == "random":
+            canon = random_weights(spec, seed=spec.dim + spec.frames)
+        elif "layers" in weights and "patch_w" in weights:
+            canon = weights
+        else:
+            canon = ingest(weights)
+        self.featurizer = HipEncoder(spec, canon, device)
+
+    def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.featurizer.forward(video_values)
+
+    @property
+    def embed_dim(self) -> int:
+        return self.spec.dim
+
+    @property
+    def num_patches(self) -> int:
+        return self.spec.num_patches
+
+    @property
+    def spatial_resolution(self) -> int:
+        return self.spec.s_out
+
+    @property
+    def temporal_resolution(self) -> int:
+        assert self.num_patches % self.spatial_resolution == 0
+        return self.num_patches // self.spatial_resolution
+
+    @property
+    def half_precision_dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+
+def random_weights(spec: EncoderSpec, seed: int) -> Dict:
+    """Seeded synthetic parameters in canonical layout (fp32 CPU)."""
+    g = torch.Generator().manual_seed(seed)
+    D, Mh = spec.dim, spec.mlp_dim
+
+    def rn(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    P = spec.s_out * (spec.t_out if spec.joint_space_time else 1)
+    out = {"patch_w": rn(D, spec.k_true, std=spec.k_true**-0.5), "pos": rn(P, D), "layers": []}
+    if spec.name != "languagebind":
+        out["patch_b"] = rn(D)
+    if spec.prefix_tokens:
+        out["prefix"] = rn(spec.prefix_tokens, D)
+    if spec.pre_ln:
+        out["pre_ln_w"], out["pre_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
+    if spec.final_ln:
+        out["final_ln_w"], out["final_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
+    for _ in range(spec.layers):
+        Lw = {"ln1_w": 1 + rn(D, std=0.1), "ln1_b": rn(D, std=0.1), "qkv_w": rn(3 * D, D, std=D**-0.5), "qkv_b": rn(3 * D),
+              "proj_w": rn(D, D, std=D**-0.5), "proj_b": rn(D), "ln2_w": 1 + rn(D, std=0.1), "ln2_b": rn(D, std=0.1),
+              "fc1_w": rn(Mh, D, std=D**-0.5), "fc1_b": rn(Mh), "fc2_w": rn(D, Mh, std=Mh**-0.5), "fc2_b": rn(D)}
+        if spec.layerscale:
+            Lw["ls1"], Lw["ls2"] = 0.5 + rn(D, std=0.2), 0.5 + rn(D, std=0.2)
+        if spec.temporal_frames:
+            Lw.update({"t_emb": rn(spec.temporal_frames, D, std=D**-0.5), "t_ln_w": 1 + rn(D, std=0.1),
+                       "t_ln_b": rn(D, std=0.1), "t_qkv_w": rn(3 * D, D, std=D**-0.5), "t_qkv_b": rn(3 * D),
+                       "t_proj_w": rn(D, D, std=D**-0.5), "t_proj_b": rn(D)})
+        out["layers"].append(Lw)
+    return out
+
+
+class LangBindVideoBackbone(VideoBackbone):
+    """languagebind/__init__.py:33-135 -- CLIP ViT-L/14 + temporal attention, hidden_states[-2]."""
+
+    def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
+                 num_frames: int = 8, token: Optional[str] = None, weights=None, device="cuda:0",
+                 hidden_act: str = "gelu_erf", layers: int = 23) -> None:
+        super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
+        assert "languagebind-video" in video_backbone_id, video_backbone_id
+        assert image_resize_strategy == "resize-naive"  # languagebind/__init__.py:64
+        if token != "noclass":
+            raise NotImplementedError(f"LanguageBind token selection `{token}` is not wired on the HIP path (only 'noclass')")
+        self.token = token
+        spec = EncoderSpec("languagebind", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BCFHW", 1, False,
+                           True, False, False, 8, hidden_act, 1e-5)
+        self._build(spec, weights, device, lambda sd: W.from_languagebind_vision(sd, n_layers=layers))
+
+    @property
+    def default_video_resolution(self) -> Tuple[int, int, int, int]:
+        return (3, self.num_frames, 224, 224)
+
+
+class DinoV2VideoBackbone(VideoBackbone):
+    """dinov2_video.py:27-179 -- timm vit_large_patch14_reg4_dinov2, get_intermediate_layers(n={L-2})."""
+
+    def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 23) -> None:
+        super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
+        if "all-tokens" not in video_backbone_id:
+            raise NotImplementedError(f"`{video_backbone_id}`: only the all-tokens selection is wired on the HIP path")
+        spec = EncoderSpec("dinov2", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BFCHW", 5, False, False,
+                           False, True, 0, "gelu_erf", 1e-6)
+        self._build(spec, weights, device,
+                    lambda sd: W.from_timm_vit(sd, n_layers=layers, grid=default_image_size // 14))
+
+    @property
+    def default_video_resolution(self) -> Tuple[int, int, int, int]:
+        return (self.num_frames, 3, self.default_image_size, self.default_image_size)
+
+
+class ViVITVideoBackbone(VideoBackbone):
+    """vivit.py:24-155 -- HF VivitModel (google/vivit-b-16x2-kinetics400), last_hidden_state[:, 1:]."""
+
+    def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
+                 num_frames: int = 32, weights=None, device="cuda:0", layers: int = 12) -> None:
+        super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
+        if "all-no-cls-16frames" not in video_backbone_id:
+            raise NotImplementedError(f"`{video_backbone_id}`: only all-no-cls-16frames is wired on the HIP path")
+        self.video_backbone_id = video_backbone_id
+        spec = EncoderSpec("vivit", 768, 12, 3072, layers, 16, 2, default_image_size, num_frames, "BFCHW", 1, True, False, True,
+                           False, 0, "gelu_tanh", 1e-6)
+        self._build(spec, weights, device, lambda sd: W.from_hf_vivit(sd, n_layers=layers))
+
+    @property
+    def default_video_resolution(self) -> Tuple[int, int, int, int]:
+        return (self.num_frames, 3, self.default_image_size, self.default_image_size)
+
+
+class SiglipVideoBackbone(VideoBackbone):
+    """siglip.py:35-174 -- timm vit_base_patch16_siglip_224, get_intermediate_layers(n={L-2}), no class token."""
+
+    def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 11) -> None:
+        super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
+        if "siglip-vit-b16-224px-all" not in video_backbone_id:
+            raise NotImplementedError(f"`{video_backbone_id}`: only the B/16-224 all-token selections are wired")
+        spec = EncoderSpec("siglip", 768, 12, 3072, layers, 16, 1, default_image_size, num_frames, "BFCHW", 0, False, False,
+                           False, False, 0, "gelu_erf", 1e-6)
+        self._build(spec, weights, device, lambda sd: W.from_timm_vit(sd, n_layers=layers))
+
+    @property
+    def default_video_resolution(self) -> Tuple[int, int, int, int]:
+        return (self.num_frames, 3, self.default_image_size, self.default_image_size)
+
+
+# === Video Backbone Registry (merv/models/materialize.py:31-73) -- same keys, same kwargs ===
+VIDEO_BACKBONES = {
+    "dinov2-video": {"cls": DinoV2VideoBackbone, "kwargs": {"default_image_size": 224}},
+    "dinov2-video-all-tokens": {"cls": DinoV2VideoBackbone, "kwargs": {"default_image_size": 224}},
+    "dinov2-video-all-token-with-cls": {"cls": DinoV2VideoBackbone, "kwargs": {"default_image_size": 224}},
+    "dinov2-video-classemb-at-first": {"cls": DinoV2VideoBackbone, "kwargs": {"default_image_size": 224}},
+    "languagebind-video": {"cls": LangBindVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "languagebind-video-averagetoken": {"cls": LangBindVideoBackbone, "kwargs": {"default_image_size": 224, "token": "average"}},
+    "languagebind-video-classemb": {"cls": LangBindVideoBackbone, "kwargs": {"default_image_size": 224, "token": "classemb"}},
+    "languagebind-video-noclass": {"cls": LangBindVideoBackbone, "kwargs": {"default_image_size": 224, "token": "noclass"}},
+    "languagebind-video-classemb-at-first": {"cls": LangBindVideoBackbone,
+                                             "kwargs": {"default_image_size": 224, "token": "classemb-at-first"}},
+    "vivit-google-b-cls-token": {"cls": ViVITVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "vivit-google-b-all-tokens": {"cls": ViVITVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "vivit-google-b-all-no-cls": {"cls": ViVITVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "vivit-google-b-all-no-cls-16frames": {"cls": ViVITVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "vivit-google-b-classemb-at-first-16frames": {"cls": ViVITVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "siglip-vit-b16-224px": {"cls": SiglipVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "siglip-vit-b16-224px-all-tokens": {"cls": SiglipVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "siglip-vit-b16-224px-all-no-cls": {"cls": SiglipVideoBackbone, "kwargs": {"default_image_size": 224}},
+    "siglip-vit-b16-224px-classemb-at-first": {"cls": SiglipVideoBackbone, "kwargs": {"default_image_size": 224}},
+}
+
+
+def get_video_backbone_and_transform(video_backbone_ids: List[str], image_resize_strategy: str, num_frames: List[int],
+                                     weights: Optional[List] = None, device="cuda:0"):
+    """materialize.py:107-129. `weights[i]`: state dict / canonical dict / "random" for backbone i."""
+    video_backbones, video_transforms = [], []
+    for i, (video_backbone_id, num_frame) in enumerate(zip(video_backbone_ids, num_frames)):
+        if video_backbone_id in VIDEO_BACKBONES:
+            cfg = VIDEO_BACKBONES[video_backbone_id]
+            bb = cfg["cls"](video_backbone_id, image_resize_strategy, num_frames=num_frame,
+                            weights=None if weights is None else weights[i], device=device, **cfg["kwargs"])
+            video_backbones.append(bb)
+            video_transforms.append(bb.get_video_transform())
+        else:
+            raise ValueError(f"Video Backbone `{video_backbone_id}` is not supported!")
+    return video_backbones, video_transforms

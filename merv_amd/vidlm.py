@@ -1,0 +1,128 @@
+"""
+MERVVisual: the visual branch of the reference's MERV VidLM (merv/models/vidlms/merv.py) with the same constructor
+vocabulary (`arch_specifier`, `feature_fusion`, `projector_token_length`, `visual_feature_length`), the same module
+names (`projectors`, `feature_fusion`) and therefore the same checkpoint keys (merv.py:272-289), running on the HIP
+path. The LLM stays outside (PyTorch-ROCm): `forward_visual` returns what MERV.forward hands to
+`llm_backbone(inputs_embeds=...)` (merv.py:723-734).
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .backbones import VideoBackbone
+from .projector import AveragePooling3DProjector, CrossAttentionAdapterLearnableQuery, splice
+
+IGNORE_INDEX = -100
+
+
+class MERVVisual(nn.Module):
+    def __init__(self, video_backbones: Sequence[VideoBackbone], llm_dim: int = 4096, arch_specifier: str = "3davg+linear",
+                 feature_fusion: Optional[str] = "cross_attention_avg_lq", projector_token_length: int = 64,
+                 visual_feature_length: int = 1024, concurrent_streams: bool = True) -> None:
+        super().__init__()
+        self.video_backbones = list(video_backbones)  # frozen, not registered as sub-modules (merv.py:315-381)
+        self.feature_fusion_type = feature_fusion
+        torch.manual_seed(self.video_backbones[0].embed_dim)  # merv.py:87: projector-init consistency
+        self.arch_specifier = arch_specifier
+        if not arch_specifier.endswith("linear"):
+            raise ValueError(f"MERV with `{arch_specifier = }` is not supported on the HIP path (only '...+linear')!")
+        parts = arch_specifier.split("+")
+        if "3davg" not in parts:
+            raise ValueError(f"MERV with `{arch_specifier = }` is not supported on the HIP path (only '3davg')!")
+        factor = 1
+        if "frame" in arch_specifier:  # merv.py:114-117
+            factor = int(re.search(r"frame(\d+)", arch_specifier).group(1))
+        if factor != 1:
+            raise NotImplementedError("temporal down-sampling projectors (frameN) are not used by merv-full")
+        out_size = int(projector_token_length**0.5)
+        assert projector_token_length == out_size**2, "projector_token_length should be square number"
+        self.tokens_resampled = True
+        self.projectors = nn.ModuleList([
+            AveragePooling3DProjector(vb.embed_dim, llm_dim, output_frames=vb.temporal_resolution // factor,
+                                      output_size=out_size, mlp_type="linear") for vb in self.video_backbones])
+        if len(self.video_backbones) > 1:  # merv.py:175-185
+            assert all(p.output_token_length * p.output_frame_length in [1, visual_feature_length] for p in self.projectors), (
+                "Output token length is not consistent across all projectors!" f" visual_feature_length={visual_feature_length}.")
+        else:
+            visual_feature_length = self.projectors[0].output_token_length * self.projectors[0].output_frame_length
+        self.visual_feature_length = visual_feature_length
+        if feature_fusion == "cross_attention_avg_lq":  # merv.py:213-216
+            self.feature_fusion = CrossAttentionAdapterLearnableQuery(embed_dim=3072, llm_dim=llm_dim,
+                                                                      token_length=visual_feature_length, averagetoken=True)
+        elif feature_fusion is None:
+            self.feature_fusion = None
+        else:
+            raise NotImplementedError(f'feature_fusion "{feature_fusion}" is not wired on the HIP path')
+        self.concurrent = concurrent_streams and len(self.video_backbones) > 1
+        self._streams: List[torch.cuda.Stream] = []
+
+    # -- checkpoint layout of the reference: {"model": {"projectors": {...}, "feature_fusion": {...}, "llm_backbone": ...}}
+    def load_from_checkpoint_dict(self, model_state_dict: Dict) -> None:
+        sd = dict(model_state_dict)
+        if "projector" in sd:  # legacy single-projector checkpoints (merv.py:273-274)
+            sd["projectors"] = {"0." + k: v for k, v in sd["projector"].items()}
+        self.projectors.load_state_dict(sd["projectors"])
+        if self.feature_fusion is not None:
+            if "feature_fusion" in sd:
+                self.feature_fusion.load_state_dict(sd["feature_fusion"])
+            elif "adapter" in sd:
+                self.feature_fusion.load_state_dict(sd["adapter"])
+            self.feature_fusion._u = None
+        for p in self.projectors:
+            p._dev = None
+
+    @torch.no_grad()
+    def encode(self, video_values: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """merv.py:562-612: encoders -> [B,T,S,C] -> projectors -> fusion. Returns (fused [B, L, llm], weights [B,E]|None)."""
+        if len(video_values) != len(self.video_backbones):
+            raise RuntimeError("Invalid `forward()` call!")  # merv.py:540-541
+        dev = video_values[0].device
+        main = torch.cuda.current_stream(dev)
+        if self.concurrent and not self._streams:
+            self._streams = [torch.cuda.Stream(dev) for _ in self.video_backbones]
+        projected = []
+        start = torch.cuda.Event()
+        start.record(main)
+        for i, (vb, proj, pix) in enumerate(zip(self.video_backbones, self.projectors, video_values)):
+            st = self._streams[i] if self.concurrent else main
+            if self.concurrent:
+                st.wait_event(start)
+            with torch.cuda.stream(st):
+                feats = vb(pix, None)  # [B, T*S, C]
+                feats = feats.reshape(-1, vb.temporal_resolution, vb.spatial_resolution, feats.shape[-1])  # :576-585
+                out = proj(feats)
+                if self.concurrent:
+                    feats.record_stream(st)
+                    out.record_stream(main)
+            projected.append(out)
+            if self.concurrent:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+        if self.feature_fusion_type is None:
+            if len(projected) != 1:
+                raise TypeError("argument of type 'NoneType' is not iterable")  # reference behaviour, merv.py:607 (App. B.4)
+            return projected[0], None
+        fused, w = self.feature_fusion(projected)
+        return fused, w
+
+    @torch.no_grad()
+    def forward_visual(self, video_values: Sequence[torch.Tensor], input_embeddings: torch.Tensor,
+                       attention_mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                       bos_token_length: int = 1):
+        """merv.py:595-664: fused tokens spliced after BOS; attention mask True / labels IGNORE_INDEX over the visual span."""
+        fused, w = self.encode(video_values)
+        emb = splice(input_embeddings, fused, bos_token_length)
+        b = bos_token_length
+        am = lab = None
+        if attention_mask is not None:
+            vis = torch.full(fused.shape[:2], True, dtype=attention_mask.dtype, device=attention_mask.device)
+            am = torch.cat([attention_mask[:, :b], vis, attention_mask[:, b:]], dim=1)
+        if labels is not None:
+            vis = torch.full(fused.shape[:2], IGNORE_INDEX, dtype=labels.dtype, device=labels.device)
+            lab = torch.cat([labels[:, :b], vis, labels[:, b:]], dim=1)
+        return emb, am, lab, w

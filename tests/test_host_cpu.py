@@ -113,3 +113,29 @@ def test_plan_units_properties():
     # north_star's literal placement: 4 GPUs, 1 video -> one encoder per GPU
     p = plan_units(costs, 1, 4)
     assert sorted(u[0][0] for u in p) == [0, 1, 2, 3] and all(len(u) == 1 for u in p)
+
+
+def test_registry_keys_and_unwired_variants():
+    from merv_amd.backbones import VIDEO_BACKBONES, get_video_backbone_and_transform
+    for k in ("languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-google-b-all-no-cls-16frames",
+              "siglip-vit-b16-224px-all-no-cls", "dinov2-video", "languagebind-video-classemb"):
+        assert k in VIDEO_BACKBONES
+    with pytest.raises(ValueError, match="is not supported"):
+        get_video_backbone_and_transform(["no-such-backbone"], "resize-naive", [8])
+    with pytest.raises(NotImplementedError):
+        VIDEO_BACKBONES["languagebind-video-classemb"]["cls"]("languagebind-video-classemb", "resize-naive", num_frames=8,
+                                                              weights="random", device="cpu",
+                                                              **VIDEO_BACKBONES["languagebind-video-classemb"]["kwargs"])
+    with pytest.raises(ValueError, match="no hub access"):
+        VIDEO_BACKBONES["siglip-vit-b16-224px-all-no-cls"]["cls"]("siglip-vit-b16-224px-all-no-cls", "resize-naive", num_frames=8)
+
+
+def test_mervvisual_rejects_unsupported_arch():
+    from merv_amd.vidlm import MERVVisual
+
+    class FakeBB:
+        embed_dim, temporal_resolution = 64, 16
+    with pytest.raises(ValueError):
+        MERVVisual([FakeBB()], arch_specifier="gelu-mlp")
+    with pytest.raises(ValueError):
+        MERVVisual([FakeBB()], arch_specifier="avg+linear")

@@ -1,0 +1,71 @@
+"""GPU: the reference-shaped front door (registry -> VideoBackbone classes -> MERVVisual) against the oracle.
+Config 1 of BASELINE.json (DINOv2-only single-encoder model, 4 frames) and a reduced-depth merv-full."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_cfg(spec):
+    from oracle import merv_oracle as O
+    return O.EncoderCfg(**{k: getattr(spec, k) for k in O.EncoderCfg.__dataclass_fields__})
+
+
+def test_config1_dinov2_single_4_frames(dev):
+    from oracle import merv_oracle as O
+    from merv_amd.backbones import VIDEO_BACKBONES
+    from merv_amd.vidlm import MERVVisual
+    cfg = VIDEO_BACKBONES["dinov2-video-all-tokens"]
+    bb = cfg["cls"]("dinov2-video-all-tokens", "resize-naive", num_frames=4, weights="random", device=dev, layers=2,
+                    **cfg["kwargs"])
+    bbs = [bb]
+    assert (bb.embed_dim, bb.num_patches, bb.spatial_resolution, bb.temporal_resolution) == (1024, 4 * 256, 256, 4)
+    assert bb.default_video_resolution == (4, 3, 224, 224)
+    m = MERVVisual(bbs, llm_dim=512, visual_feature_length=512)  # single encoder: length is corrected to 4*64 (merv.py:194-205)
+    assert m.visual_feature_length == 256
+    g = torch.Generator().manual_seed(0)
+    pix = torch.randn(1, 4, 3, 224, 224, generator=g)
+    emb = torch.randn(1, 7, 512, generator=g).to(torch.bfloat16)
+    am = torch.ones(1, 7, dtype=torch.bool)
+    out, mask, _, w = m.forward_visual([pix.to(dev)], emb.to(dev), am.to(dev))
+    assert out.shape == (1, 7 + 256, 512) and mask.shape == (1, 263) and bool(mask.all())
+    assert torch.allclose(w.cpu(), torch.ones(1, 1))  # one encoder: fusion weight == 1, fused == projected
+    # oracle with the very same parameters
+    from merv_amd.backbones import random_weights
+    Wc = random_weights(bb.spec, seed=bb.spec.dim + bb.spec.frames)
+    tok = O.encoder_forward(pix, _oracle_cfg(bb.spec), Wc)
+    lin = m.projectors[0].projector.projector
+    ref = O.projector_forward(tok, 4, 16, 8, lin.weight.detach(), lin.bias.detach())
+    assert rel_l2(out[:, 1:257], ref) < 2e-2
+    assert torch.equal(out[:, :1].cpu(), emb[:, :1]) and torch.equal(out[:, 257:].cpu(), emb[:, 1:])
+
+
+def test_merv_full_reduced_depth_through_registry(dev):
+    from oracle import merv_oracle as O
+    from merv_amd.backbones import VIDEO_BACKBONES, random_weights
+    from merv_amd.vidlm import MERVVisual
+    ids = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-google-b-all-no-cls-16frames",
+           "siglip-vit-b16-224px-all-no-cls"]  # merv/conf/models.py:106-113
+    frames = [16, 16, 32, 16]
+    bbs = [VIDEO_BACKBONES[i]["cls"](i, "resize-naive", num_frames=f, weights="random", device=dev, layers=1,
+                                     **VIDEO_BACKBONES[i]["kwargs"]) for i, f in zip(ids, frames)]
+    m = MERVVisual(bbs, llm_dim=1024, visual_feature_length=1024)
+    with torch.no_grad():
+        m.feature_fusion.Q.mul_(30)
+    g = torch.Generator().manual_seed(1)
+    pix = [torch.randn(b.default_video_resolution, generator=g)[None] for b in bbs]
+    fused, w = m.encode([p.to(dev) for p in pix])
+    torch.cuda.synchronize()
+    projected = []
+    for b, p, pr in zip(bbs, pix, m.projectors):
+        Wc = random_weights(b.spec, seed=b.spec.dim + b.spec.frames)
+        tok = O.encoder_forward(p, _oracle_cfg(b.spec), Wc)
+        lin = pr.projector.projector
+        projected.append(O.projector_forward(tok, 16, b.spec.hp, 8, lin.weight.detach(), lin.bias.detach()))
+    Fw = {k: v.detach() for k, v in m.feature_fusion.state_dict().items()}
+    ref, wref = O.fusion_forward(projected, Fw)
+    assert fused.shape == (1, 1024, 1024)
+    assert (w.cpu() - wref).abs().max() < 5e-3
+    assert rel_l2(fused, ref) < 2e-2
