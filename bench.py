@@ -129,6 +129,12 @@ def cpu_baseline(budget_layers=2, threads=None):
 
 
 def main():
+    # Native libraries (RCCL's version banner, rocm warnings) print to fd 1; the contract is ONE JSON line on stdout, so
+    # everything else is sent to stderr and the JSON goes to a private copy of the original stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -163,7 +169,12 @@ def main():
     B = args.batch
     G = B * world
 
-    if world == 1:
+    force_dist = os.environ.get("MERV_BENCH_FORCE_DISTRIBUTED") == "1"  # exercise the N>1 code path on one GPU
+    if world == 1 and force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    if world == 1 and not force_dist:
         pixels = synth_pixels(specs, B, device, seed=rank)
 
         def step():
@@ -199,7 +210,7 @@ def main():
     # Kernel durations are only well defined when kernels do not overlap, so this pass runs the encoders on ONE
     # stream (the throughput above is measured with concurrent streams and no events).
     roof = None
-    if not args.no_prof and world == 1:
+    if not args.no_prof and world == 1 and not force_dist:
         was = path.concurrent
         path.concurrent = False
         step(); torch.cuda.synchronize()
@@ -255,8 +266,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        print(json.dumps(line), file=real_stdout, flush=True)
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
