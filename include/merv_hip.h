@@ -156,7 +156,8 @@ int merv_im2col(const void *pix, int32_t pix_dtype, void *out, int32_t B, int32_
 int merv_pool3d(const void *tokens, void *out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
                 void *stream);
 
-/* Tuning / test hook: force the GEMM tile configuration (0 auto, 1: 128x128, 2: 256x256, 3: 256x128). */
+/* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128,
+ * 4 / 5: the staggered forms of 3 / 2; second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
 
 /*

@@ -42,6 +42,98 @@ MERV_DEVICE void dma_rows8(const bf16_t* __restrict__ g, int ld, int row0, int r
                                      (__attribute__((address_space(3))) void*)(lds_tile + rowblk * 1024), 16, 0, 0);
 }
 
+// ---- epilogue (shared by all tile configurations) ----
+template <int WTM, int WTN, bool REMAP, int ACT>
+MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM / 16], char* smem, int wave, int lane, int m0,
+                               int n0, int wr, int wc) {
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    const int frow = lane & 15, fq = lane >> 4;
+    // The accumulators hold D^T fragments (4 consecutive n per lane, 32-byte row segments per instruction): stored
+    // straight to global memory that costs ~6 us per 256x128 tile (partial-line accesses), as much as 7 K-steps.
+    // Instead each wave transposes its WTM x 64 sub-tile through its own LDS region (the stage ring is free now)
+    // and reads it back row-contiguous: every global access of the epilogue is then 16 B per lane, 128 B per row.
+    // Residual rows are loaded the same way BEFORE the transpose so their latency hides under it; C may alias the
+    // residual (x += ...), which is safe because each element is read and written by the same lane.
+    static_assert(WTN == 64, "epilogue staging assumes 64-column wave tiles");
+    constexpr int EP_IT = WTM / 8;  // 16-byte chunks per lane: WTM rows x 8 chunks / 64 lanes
+    const int wn0 = n0 + wc * WTN;
+    uint32_t c_off[EP_IT];  // element offsets (the launcher checks they fit 32 bits)
+    bool valid[EP_IT];
+    u32x4 resv[EP_IT];
+    // opaque copy of the lane id: keeps the compiler from hoisting the epilogue's index arithmetic (integer
+    // divisions) above the K-loop, where it would sit in registers -- or scratch -- for the whole kernel
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int ec = elane & 7;  // this lane's 16-byte chunk (8 columns) of each row it handles
+    uint32_t r_off[EP_IT];
+#pragma unroll
+    for (int it = 0; it < EP_IT; ++it) {
+        const int r = (elane >> 3) + 8 * it;
+        const int m = m0 + wr * WTM + r;
+        valid[it] = m < p.M;
+        const int mc = valid[it] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
+        int orow = mc, rr = mc;
+        if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
+            if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
+            if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
+        }
+        c_off[it] = (uint32_t)orow * (uint32_t)p.ldc + wn0 + ec * 8;
+        r_off[it] = (uint32_t)rr * (uint32_t)p.ldres + wn0 + ec * 8;
+    }
+    // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
+    // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
+    if (p.res) {
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
+    } else {
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
+    }
+    float4 bias4[NI], ls4[NI];
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bias4[i] = *(const float4*)(p.bias + wn0 + i * 16 + fq * 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) bias4[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.lscale) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ls4[i] = *(const float4*)(p.lscale + wn0 + i * 16 + fq * 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ls4[i] = float4{1.f, 1.f, 1.f, 1.f};
+    }
+    // every wave is done with the stage ring
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const f32x4 v = acc[i][j];
+            u32x2 o;
+            o[0] = pack2bf(activate<ACT>(v[0] + bias4[i].x) * ls4[i].x, activate<ACT>(v[1] + bias4[i].y) * ls4[i].y);
+            o[1] = pack2bf(activate<ACT>(v[2] + bias4[i].z) * ls4[i].z, activate<ACT>(v[3] + bias4[i].w) * ls4[i].w);
+            const int row = j * 16 + frow;
+            const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
+            *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
+#pragma unroll
+    for (int it = 0; it < EP_IT; ++it) {
+        const int r = (elane >> 3) + 8 * it;
+        u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
+        if (p.res) {
+            // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
+        }
+        if (valid[it]) *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+    }
+}
+
 template <int N>
 MERV_DEVICE void wait_dma_barrier() {
     // my DMAs except the youngest N have landed and my LDS reads have returned; after the barrier that holds for
@@ -75,7 +167,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / BN;
     const int nwg = tilesM * tilesN;
     const int id = xcd_remap(blockIdx.x, nwg);
-    constexpr int GM = (BM >= 256) ? 4 : 8;
+    const int GM = p.group_m > 0 ? p.group_m : ((BM >= 256) ? 4 : 8);
     const int per_group = GM * tilesN;
     const int grp = id / per_group;
     const int first_m = grp * GM;
@@ -208,307 +300,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
         mma_half(haf, hwf, 0, 0, 0, std::false_type{});
     }
 
-    // ---- epilogue ----
-    // The accumulators hold D^T fragments (4 consecutive n per lane, 32-byte row segments per instruction): stored
-    // straight to global memory that costs ~6 us per 256x128 tile (partial-line accesses), as much as 7 K-steps.
-    // Instead each wave transposes its WTM x 64 sub-tile through its own LDS region (the stage ring is free now)
-    // and reads it back row-contiguous: every global access of the epilogue is then 16 B per lane, 128 B per row.
-    // Residual rows are loaded the same way BEFORE the transpose so their latency hides under it; C may alias the
-    // residual (x += ...), which is safe because each element is read and written by the same lane.
-    static_assert(WTN == 64, "epilogue staging assumes 64-column wave tiles");
-    constexpr int EP_IT = WTM / 8;  // 16-byte chunks per lane: WTM rows x 8 chunks / 64 lanes
-    const int wn0 = n0 + wc * WTN;
-    uint32_t c_off[EP_IT];  // element offsets (the launcher checks they fit 32 bits)
-    bool valid[EP_IT];
-    u32x4 resv[EP_IT];
-    // opaque copy of the lane id: keeps the compiler from hoisting the epilogue's index arithmetic (integer
-    // divisions) above the K-loop, where it would sit in registers -- or scratch -- for the whole kernel
-    int elane = lane;
-    asm volatile("" : "+v"(elane));
-    const int ec = elane & 7;  // this lane's 16-byte chunk (8 columns) of each row it handles
-    uint32_t r_off[EP_IT];
-#pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-        const int r = (elane >> 3) + 8 * it;
-        const int m = m0 + wr * WTM + r;
-        valid[it] = m < p.M;
-        const int mc = valid[it] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
-        int orow = mc, rr = mc;
-        if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
-            if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
-            if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
-        }
-        c_off[it] = (uint32_t)orow * (uint32_t)p.ldc + wn0 + ec * 8;
-        r_off[it] = (uint32_t)rr * (uint32_t)p.ldres + wn0 + ec * 8;
-    }
-    // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
-    // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
-    if (p.res) {
-#pragma unroll
-        for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
-    } else {
-#pragma unroll
-        for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
-    }
-    float4 bias4[NI], ls4[NI];
-    if (p.bias) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bias4[i] = *(const float4*)(p.bias + wn0 + i * 16 + fq * 4);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bias4[i] = float4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (p.lscale) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) ls4[i] = *(const float4*)(p.lscale + wn0 + i * 16 + fq * 4);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) ls4[i] = float4{1.f, 1.f, 1.f, 1.f};
-    }
-    // every wave is done with the stage ring
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const f32x4 v = acc[i][j];
-            u32x2 o;
-            o[0] = pack2bf(activate<ACT>(v[0] + bias4[i].x) * ls4[i].x, activate<ACT>(v[1] + bias4[i].y) * ls4[i].y);
-            o[1] = pack2bf(activate<ACT>(v[2] + bias4[i].z) * ls4[i].z, activate<ACT>(v[3] + bias4[i].w) * ls4[i].w);
-            const int row = j * 16 + frow;
-            const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
-            *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
-#pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-        const int r = (elane >> 3) + 8 * it;
-        u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
-        if (p.res) {
-            // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
-        }
-        if (valid[it]) *(u32x4*)(p.C + (size_t)c_off[it]) = t;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Persistent variant: one block per CU walks its tiles (v = blockIdx.x + i * gridDim.x) and the LDS-DMA ring runs
-// straight across tile boundaries, so the next tile's first stages land while this tile's epilogue stores drain, and
-// the residual / bias loads of the epilogue are issued one K-step early. With one block per CU there is no second
-// block to hide a tile's prologue (first DMA round trip) and epilogue (residual load round trip + store drain):
-// measured, they cost ~9 us of a 23 us 256x128 tile at K = 1024 (profiles/r01_gemm_tiles.md).
-// vmcnt bookkeeping: a wait for the DMAs of step g may leave outstanding every op issued after them: the DMAs of
-// steps g+1 .. g+NSTAGE-2 and, right after an epilogue, that epilogue's NI*MI stores.
-// ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool EPI_PREFETCH, int ACT>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_persistent_kernel(GemmArgs p) {
-    constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-    constexpr int MI = WTM / 16, NI = WTN / 16;
-    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
-    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
-    constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;
-    constexpr int DPS = A_PIECES + W_PIECES;
-    constexpr int NSTORES = NI * MI;
-    constexpr int N_STEADY = (NSTAGE - 2) * DPS;
-    constexpr int N_AFTER_EPI = (N_STEADY + NSTORES) > 63 ? 63 : (N_STEADY + NSTORES);
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over waves");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 stages");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-    const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
-
-    const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / BN;
-    const int ntiles = tilesM * tilesN;
-    const int G = gridDim.x;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
-    const int nkt = p.K / BK;
-    const int total_steps = my_tiles * nkt;
-
-    auto tile_origin = [&](int i, int& m0, int& n0) {
-        const int v = blockIdx.x + i * G;
-        const int id = xcd_remap(v, ntiles);
-        constexpr int GM = (BM >= 256) ? 4 : 8;
-        const int per_group = GM * tilesN;
-        const int grp = id / per_group;
-        const int first_m = grp * GM;
-        const int gsz = (tilesM - first_m) < GM ? (tilesM - first_m) : GM;
-        const int in_grp = id - grp * per_group;
-        m0 = (first_m + in_grp % gsz) * BM;
-        n0 = (in_grp / gsz) * BN;
-    };
-
-    // ---- producer state: the next (tile, kt) whose DMAs have not been issued yet ----
-    int p_tile = 0, p_kt = 0, p_buf = 0, p_m0, p_n0, p_step = 0;
-    tile_origin(0, p_m0, p_n0);
-    auto dma_piece = [&](int pc) {
-        char* a_tile = smem + p_buf * STAGE_BYTES;
-        if (pc < A_PIECES) dma_rows8(p.A, p.lda, p_m0, p.M - 1, pc * NW + wave, p_kt * BK, a_tile, lane);
-        else dma_rows8(p.W, p.ldw, p_n0, p.N - 1, (pc - A_PIECES) * NW + wave, p_kt * BK, a_tile + A_BYTES, lane);
-    };
-    auto advance_producer = [&]() {
-        ++p_step;
-        p_buf = p_buf + 1 == NSTAGE ? 0 : p_buf + 1;
-        if (++p_kt == nkt) {
-            p_kt = 0;
-            ++p_tile;
-            if (p_tile < my_tiles) tile_origin(p_tile, p_m0, p_n0);
-        }
-    };
-#pragma unroll
-    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (p_step < total_steps) {
-#pragma unroll
-            for (int pc = 0; pc < DPS; ++pc) dma_piece(pc);
-            advance_producer();
-        }
-
-    f32x4 acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int c_buf = 0, g = 0;
-    for (int ti = 0; ti < my_tiles; ++ti) {
-        int m0, n0;
-        tile_origin(ti, m0, n0);
-        // epilogue operands: bias + residual are loaded during the tile's last K-step when registers allow
-        float4 bias4[NI];
-        u32x2 resv[NI][MI];
-        size_t c_off[MI];
-        bool valid[MI];
-
-        auto load_epilogue_operands = [&]() {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int n = n0 + wc * WTN + i * 16 + fq * 4;
-                bias4[i] = p.bias ? *(const float4*)(p.bias + n) : float4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int m = m0 + wr * WTM + j * 16 + frow;
-                valid[j] = m < p.M;
-                int orow = m;
-                if (p.out_group > 0) orow = (m / p.out_group) * p.out_stride + p.out_off + (m % p.out_group);
-                c_off[j] = (size_t)orow * p.ldc;
-                if (p.res) {
-                    const int rr = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-                    const bf16_t* rrow = p.res + (size_t)rr * p.ldres + n0 + wc * WTN + fq * 4;
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) resv[i][j] = valid[j] ? *(const u32x2*)(rrow + i * 16) : u32x2{0u, 0u};
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) resv[i][j] = u32x2{0u, 0u};
-                }
-            }
-        };
-
-        auto k_step = [&](auto prefetch_tag) {
-            constexpr bool PREFETCH = decltype(prefetch_tag)::value;
-            const char* a_tile = smem + c_buf * STAGE_BYTES + (wr * WTM + frow) * ROW_BYTES;
-            const char* w_tile = smem + c_buf * STAGE_BYTES + A_BYTES + (wc * WTN + frow) * ROW_BYTES;
-#pragma unroll
-            for (int kk = 0; kk < BK / 32; ++kk) {
-                const int coff = (((kk * 4) + fq) ^ sw) * 16;
-                bf16x8 af[MI], wf[NI];
-#pragma unroll
-                for (int j = 0; j < MI; ++j) af[j] = *(const bf16x8*)(a_tile + j * 16 * ROW_BYTES + coff);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) wf[i] = *(const bf16x8*)(w_tile + i * 16 * ROW_BYTES + coff);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-#pragma unroll
-                    for (int j = 0; j < MI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                    if constexpr (PREFETCH) {
-                        constexpr int ROWS = (BK / 32) * NI;
-                        const int r = kk * NI + i;
-#pragma unroll
-                        for (int pc = 0; pc < DPS; ++pc)
-                            if (pc * ROWS / DPS == r) dma_piece(pc);
-                    }
-                }
-            }
-            if constexpr (PREFETCH) advance_producer();
-            c_buf = c_buf + 1 == NSTAGE ? 0 : c_buf + 1;
-        };
-
-        for (int kt = 0; kt < nkt; ++kt, ++g) {
-            const int younger = total_steps - 1 - g;  // steps whose DMAs may legitimately still be in flight
-            if (younger >= NSTAGE - 2) {
-                // steady state; right after an epilogue its stores are younger than the DMAs we wait for
-                if (ti > 0 && kt < NSTAGE - 1) wait_dma_barrier<N_AFTER_EPI>();
-                else wait_dma_barrier<N_STEADY>();
-            } else if (younger == 1) {
-                wait_dma_barrier<DPS>();
-            } else {
-                wait_dma_barrier<0>();
-            }
-            if (EPI_PREFETCH && kt == nkt - 1) load_epilogue_operands();
-            if (p_step < total_steps) k_step(std::true_type{});
-            else k_step(std::false_type{});
-        }
-
-        // ---- epilogue (bias / residual are already in registers or in flight when EPI_PREFETCH) ----
-        if (!EPI_PREFETCH) load_epilogue_operands();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = n0 + wc * WTN + i * 16 + fq * 4;
-            const float4 ls = p.lscale ? *(const float4*)(p.lscale + n) : float4{1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                f32x4 v = acc[i][j];
-                v[0] = activate<ACT>(v[0] + bias4[i].x) * ls.x + bflo(resv[i][j][0]);
-                v[1] = activate<ACT>(v[1] + bias4[i].y) * ls.y + bfhi(resv[i][j][0]);
-                v[2] = activate<ACT>(v[2] + bias4[i].z) * ls.z + bflo(resv[i][j][1]);
-                v[3] = activate<ACT>(v[3] + bias4[i].w) * ls.w + bfhi(resv[i][j][1]);
-                u32x2 o;
-                o[0] = pack2bf(v[0], v[1]);
-                o[1] = pack2bf(v[2], v[3]);
-                if (valid[j]) *(u32x2*)(p.C + c_off[j] + n) = o;
-                acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    }
-}
-
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool EPI_PREFETCH, int ACT>
-hipError_t launch_persistent(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = NSTAGE * (BM + BN) * ROW_BYTES;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = gemm_bf16_persistent_kernel<BM, BN, WM, WN, NSTAGE, EPI_PREFETCH, ACT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int ntiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const int per_cu = LDS <= 80 * 1024 ? 2 : 1;
-    int grid = num_cus() * per_cu;
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), LDS, s, a);
-    return hipGetLastError();
+    gemm_epilogue<WTM, WTN, REMAP, ACT>(p, acc, smem, wave, lane, m0, n0, wr, wc);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT>
@@ -537,7 +329,8 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT>(a, s);
 }
 
-int g_gemm_variant = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
+int g_gemm_variant = 0;
+int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
 // Tile choice (measured on MI355X, tools/gemm_bench.py, profiles/r01_gemm_tiles.md): the 256x128 tile with a 3-deep
 // LDS ring and staggered half-blocks is the fastest configuration whenever it yields enough blocks to occupy the
@@ -556,21 +349,19 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
         case 3: return launch_cfg<256, 128, 4, 2, 3, false, ACT>(a, s);
         case 4: return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
         case 5: return launch_cfg<256, 256, 2, 4, 2, true, ACT>(a, s);
-        case 6: return launch_persistent<256, 128, 4, 2, 3, true, ACT>(a, s);
-        case 7: return launch_persistent<256, 256, 2, 4, 2, false, ACT>(a, s);
-        case 8: return launch_persistent<128, 128, 2, 2, 2, true, ACT>(a, s);
-        case 9: return launch_persistent<256, 128, 4, 2, 3, false, ACT>(a, s);
         default: return launch_cfg<128, 128, 2, 2, 2, false, ACT>(a, s);
     }
 }
 
 }  // namespace
 
-void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm_variant(int v) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
 
 // Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc % 8 == 0.
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
+hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    GemmArgs a = a_in;
+    if (g_gemm_group_m > 0) a.group_m = g_gemm_group_m;
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 8 != 0) return hipErrorInvalidValue;

@@ -9,7 +9,7 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (300, 256, 128), (4112, 1024, 1024), (33000, 768, 192), (70000, 256, 64)])
 def test_variant(dev, variant, M, N, K):
     from merv_amd import _lib, ops
