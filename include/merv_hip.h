@@ -156,6 +156,23 @@ int merv_im2col(const void *pix, int32_t pix_dtype, void *out, int32_t B, int32_
 int merv_pool3d(const void *tokens, void *out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
                 void *stream);
 
+/*
+ * Frame preprocessing on the GPU: uint8 frames [T,3,H,W] (device) -> normalised pixels.
+ *  merv_preprocess_pil: torchvision Resize((S,S)) on a PIL image + ToTensor + Normalize, i.e. the DINOv2 / SigLIP
+ *    (filter 1 = bicubic) and ViViT (filter 0 = bilinear) transforms (dinov2_video.py:76-124, siglip.py:86-134,
+ *    vivit.py:50-92). The resized uint8 image is bit-exact with Pillow's Image.resize; out [T,3,S,S] fp32 or bf16;
+ *    resized_u8 (optional, [T,3,S,S] uint8) exposes the intermediate for parity tests.
+ *  merv_preprocess_languagebind: x/255 -> (x-mean)/std -> bilinear (align_corners=False) short side S -> centre crop S
+ *    -> optional horizontal flip; out [3,T,S,S] (languagebind/video/processing_video.py:63-79; the reference flips at
+ *    random, here `flip` is explicit).
+ */
+size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t out_size);
+int merv_preprocess_pil(const void *frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t filter,
+                        const float *mean3, const float *std3, void *out_pixels, int32_t out_dtype, void *resized_u8,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t flip,
+                                 const float *mean3, const float *std3, void *out_pixels, int32_t out_dtype, void *stream);
+
 /* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128,
  * 4 / 5: the staggered forms of 3 / 2; second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);

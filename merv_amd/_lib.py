@@ -71,6 +71,9 @@ SIGNATURES = {
     "merv_temporal_attention": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_im2col": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "merv_pool3d": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "merv_preprocess_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "merv_preprocess_pil": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp, _i32, _vp, _vp, _sz, _vp]),
+    "merv_preprocess_languagebind": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp, _i32, _vp]),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_prof_enable": (None, [_i32]),
     "merv_prof_reset": (None, []),

@@ -8,8 +8,9 @@ Differences from the reference, all forced by this environment (no network, no t
   * only the token selections used by merv-full / merv-frozen and the single-encoder configs are wired
     (`*-noclass`, `*-all-tokens`, `*-all-no-cls-16frames`, `*-all-no-cls`); the other registry keys exist and raise
     NotImplementedError when constructed;
-  * `video_transform` (CPU PIL / torchvision pipelines) is the next row of the scope table and
-    is not provided here: callers hand over post-transform tensors.
+  * `video_transform` is the GPU implementation of the reference's CPU PIL / torchvision pipelines
+    (merv_amd/preprocess.py: Pillow-bit-exact resize + ToTensor + Normalize; LanguageBind's torch pipeline with the
+    random flip made an explicit, default-off switch): it takes load_video()'s uint8 [F,3,H,W] tensor on the device.
 """
 from __future__ import annotations
 
@@ -53,6 +54,9 @@ class VideoBackbone(nn.Module):
         else:
             canon = ingest(weights)
         self.featurizer = HipEncoder(spec, canon, device)
+        # the reference's per-encoder CPU transform (row a3), as HIP kernels: uint8 [F,3,H,W] -> this encoder's layout
+        from .preprocess import transform_for
+        self.video_transform = transform_for(spec.name, torch.float32)
 
     def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.featurizer.forward(video_values)

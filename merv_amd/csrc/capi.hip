@@ -281,6 +281,36 @@ extern "C" int merv_splice_forward(const void* emb, const void* vis, int32_t bat
     return 0;
 }
 
+// ---- frame preprocessing (row a3) ----
+extern "C" size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t out_size) {
+    if (T <= 0 || H <= 0 || W <= 0 || out_size <= 0) return 0;
+    return pil_workspace_bytes(T, H, W, out_size);
+}
+
+extern "C" int merv_preprocess_pil(const void* frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t filter,
+                                   const float* mean3, const float* std3, void* out_pixels, int32_t out_dtype, void* resized_u8,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    MERV_CHECK(frames_u8 && mean3 && std3 && workspace && (out_pixels || resized_u8), "merv_preprocess_pil: null argument");
+    MERV_CHECK(T > 0 && H > 0 && W > 0 && out_size > 0, "merv_preprocess_pil: bad geometry");
+    MERV_CHECK(filter == 0 || filter == 1, "merv_preprocess_pil: filter must be 0 (bilinear) or 1 (bicubic)");
+    MERV_CHECK(out_dtype == MERV_DT_F32 || out_dtype == MERV_DT_BF16, "merv_preprocess_pil: bad output dtype");
+    MERV_CHECK(((uintptr_t)workspace & 255) == 0, "merv_preprocess_pil: workspace must be 256-byte aligned");
+    MERV_CHECK(workspace_bytes >= pil_workspace_bytes(T, H, W, out_size), "merv_preprocess_pil: workspace too small");
+    MERV_HIP(launch_pil_resize_normalize((const uint8_t*)frames_u8, T, H, W, out_size, filter, mean3, std3, out_pixels,
+                                         out_dtype == MERV_DT_BF16, (uint8_t*)resized_u8, (char*)workspace, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_preprocess_languagebind(const void* frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t flip,
+                                            const float* mean3, const float* std3, void* out_pixels, int32_t out_dtype, void* stream_) {
+    MERV_CHECK(frames_u8 && mean3 && std3 && out_pixels, "merv_preprocess_languagebind: null argument");
+    MERV_CHECK(T > 0 && H > 0 && W > 0 && out_size > 0, "merv_preprocess_languagebind: bad geometry");
+    MERV_CHECK(out_dtype == MERV_DT_F32 || out_dtype == MERV_DT_BF16, "merv_preprocess_languagebind: bad output dtype");
+    MERV_HIP(launch_languagebind_transform((const uint8_t*)frames_u8, T, H, W, out_size, flip != 0, mean3, std3, out_pixels,
+                                           out_dtype == MERV_DT_BF16, (hipStream_t)stream_));
+    return 0;
+}
+
 // Tuning / test hook: force a GEMM tile configuration (0 = automatic choice).
 extern "C" void merv_debug_set_gemm_variant(int32_t v) { set_gemm_variant(v); }
 

@@ -120,4 +120,11 @@ struct SpliceArgs {
 };
 hipError_t launch_splice(const SpliceArgs& a, hipStream_t s);
 
+// Frame preprocessing (preproc.hip). kind: 0 = bilinear, 1 = bicubic (Pillow filters).
+size_t pil_workspace_bytes(int T, int H, int W, int out);
+hipError_t launch_pil_resize_normalize(const uint8_t* frames, int T, int H, int W, int out, int kind, const float* mean,
+                                       const float* sd, void* out_pix, int out_bf16, uint8_t* resized_u8_opt, char* ws, hipStream_t s);
+hipError_t launch_languagebind_transform(const uint8_t* frames, int T, int H, int W, int S, int flip, const float* mean, const float* sd,
+                                         void* out_pix, int out_bf16, hipStream_t s);
+
 }  // namespace merv

@@ -19,6 +19,9 @@ What is pinned, and against what:
   hf_crosscheck.npz    HF Dinov2WithRegistersModel / SiglipVisionModel reduced-size hidden states: a cross-check for
                        the timm-semantics restatement (timm itself is not installed: "timm parity unpinned").
   prompts.json         PurePromptBuilder strings (merv/models/backbones/llm/prompting/base_prompter.py).
+  preprocess.npz       per-encoder frame transforms: PIL.Image.resize (what torchvision Resize calls on a PIL image) for
+                       bicubic / bilinear on 7 frame sizes, ToTensor+Normalize and the LanguageBind torch pipeline,
+                       evaluated with Pillow / torch here (torchvision is absent); inputs are synthetic and regenerated.
 """
 import importlib.util
 import json
@@ -300,7 +303,7 @@ def gen_prompts():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["frames", "projfus", "lb", "vivit", "hf", "prompts"]
+    which = sys.argv[1:] or ["frames", "projfus", "lb", "vivit", "hf", "prompts", "preprocess"]
     torch.set_num_threads(8)
     if "frames" in which:
         gen_frame_indices()
@@ -314,3 +317,57 @@ if __name__ == "__main__":
         gen_hf_crosscheck()
     if "prompts" in which:
         gen_prompts()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def synth_frame(H, W, seed):
+    """Deterministic integer-only test frame [H,W,3] uint8 (regenerated identically by the tests)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    base = ((xx * 3 + yy * 5 + (xx * yy) % 7 * 9) % 256)[..., None] + np.array([0, 17, 34])
+    noise = rng.randint(0, 64, size=(H, W, 3))
+    return ((base + noise) % 256).astype(np.uint8)
+
+
+PRE_SIZES = [(96, 128), (300, 200), (231, 487), (224, 224), (224, 100), (50, 224), (720, 1280)]
+LB_SIZES = [(96, 128), (300, 200)]
+
+
+def gen_preprocess():
+    """Per-encoder CPU transforms at the level the reference reaches them: torchvision is not installed here, so
+    Resize((224,224)) on a PIL image is evaluated as what it calls -- PIL.Image.resize((224,224), resample) -- and
+    ToTensor / Normalize / NormalizeVideo / ShortSideScale / CenterCropVideo as the torch ops they are made of
+    (dinov2_video.py:94-124, siglip.py:104-134, vivit.py:54-92, processing_video.py:28-79). Inputs are synthetic and
+    regenerated by the tests from (H, W, seed); only outputs are stored."""
+    from PIL import Image
+    out = {"sizes": np.array(PRE_SIZES), "lb_sizes": np.array(LB_SIZES)}
+    for i, (H, W) in enumerate(PRE_SIZES):
+        pil = Image.fromarray(synth_frame(H, W, 100 + i), "RGB")
+        for name, flt in (("bicubic", Image.BICUBIC), ("bilinear", Image.BILINEAR)):
+            out[f"img{i}_{name}_u8"] = np.asarray(pil.resize((224, 224), flt)).transpose(2, 0, 1).copy()
+    # float stages: ToTensor + Normalize (fp32 torch ops) on one resized image, stored as a thin slice
+    t = torch.from_numpy(out["img1_bicubic_u8"].copy()).to(torch.float32).div(255)
+    mean = torch.tensor((0.485, 0.456, 0.406)).view(3, 1, 1)
+    std = torch.tensor((0.229, 0.224, 0.225)).view(3, 1, 1)
+    out["img1_dinov2_pix_rows"] = t.clone().sub_(mean).div_(std)[:, ::16].numpy()
+    # LanguageBind pipeline (flip off) on 2-frame clips
+    for j, (H, W) in enumerate(LB_SIZES):
+        frames = np.stack([synth_frame(H, W, 200 + 10 * j + f) for f in range(2)], 0)  # [T, H, W, 3]
+        clip = torch.from_numpy(frames).permute(3, 0, 1, 2)  # [C, T, H, W] == video.permute(1,0,2,3) of [T,C,H,W]
+        x = clip / 255.0
+        m = torch.tensor((0.48145466, 0.4578275, 0.40821073)); sd = torch.tensor((0.26862954, 0.26130258, 0.27577711))
+        x = x.clone().sub_(m[:, None, None, None]).div_(sd[:, None, None, None])
+        c, t_, h, w = x.shape
+        if w < h:
+            new_h, new_w = int(math.floor((float(h) / w) * 224)), 224
+        else:
+            new_h, new_w = 224, int(math.floor((float(w) / h) * 224))
+        x = torch.nn.functional.interpolate(x, size=(new_h, new_w), mode="bilinear", align_corners=False)
+        i0, j0 = int(round((new_h - 224) / 2.0)), int(round((new_w - 224) / 2.0))
+        out[f"lb{j}_out"] = x[..., i0:i0 + 224, j0:j0 + 224].numpy().astype(np.float32)
+    np.savez_compressed(OUT / "preprocess.npz", **out)
+    print("preprocess: ok", len(out), "arrays")
+
+
+if __name__ == "__main__" and ("preprocess" in sys.argv[1:] or not sys.argv[1:]):
+    gen_preprocess()
