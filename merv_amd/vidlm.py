@@ -126,3 +126,56 @@ class MERVVisual(nn.Module):
             vis = torch.full(fused.shape[:2], IGNORE_INDEX, dtype=labels.dtype, device=labels.device)
             lab = torch.cat([labels[:, :b], vis, labels[:, b:]], dim=1)
         return emb, am, lab, w
+
+
+class MERV(MERVVisual):
+    """MERVVisual + an LLM backbone: the reference's front door `generate(video, prompt_text, num_frames, **kwargs)`
+    (merv.py:778-830) with an explicit prefill + decode loop.
+
+    `tokenizer` is any callable object with `__call__(text) -> list[int]` (incl. BOS) and `decode(ids) -> str`; HF
+    tokenizers are adapted by `HFTokenizerAdapter`. (The Llama tokenizer files cannot be fetched here.)"""
+
+    def __init__(self, video_backbones, llm_backbone, tokenizer=None, **kw) -> None:
+        super().__init__(video_backbones, llm_dim=llm_backbone.embed_dim, **kw)
+        self.llm_backbone = llm_backbone
+        self.tokenizer = tokenizer
+
+    def get_prompt_builder(self, system_prompt=None, chat: bool = False):
+        from .prompting import LLaMa2ChatPromptBuilder, PurePromptBuilder
+        return (LLaMa2ChatPromptBuilder if chat else PurePromptBuilder)("merv", system_prompt=system_prompt)
+
+    @torch.inference_mode()
+    def generate(self, video, prompt_text, num_frames, **kwargs):
+        assert len(num_frames) == len(self.video_backbones), "Number of frames should match number of video backbones!"
+        from .sampler import temporal_subsample
+        from .video_io import load_video
+        dev = self.llm_backbone.device
+        if isinstance(prompt_text, str):
+            if self.tokenizer is None:
+                raise ValueError("generate(prompt_text: str) needs a tokenizer; pass token ids otherwise")
+            input_ids = torch.tensor([self.tokenizer(prompt_text)], dtype=torch.long, device=dev)
+        else:
+            input_ids = torch.as_tensor(prompt_text, dtype=torch.long, device=dev).reshape(1, -1)
+        clip_start_sec = kwargs.pop("clip_start_sec", 0.0)
+        clip_end_sec = kwargs.pop("clip_end_sec", None)
+        end_frame = kwargs.pop("end_frame", None)
+        if video is not None:
+            frames = load_video(video, clip_start_sec=clip_start_sec, clip_end_sec=clip_end_sec, num_frames=max(num_frames),
+                                end_frame=end_frame).to(dev)  # uint8 [T,3,H,W]
+            video_values = []
+            for vb, nf in zip(self.video_backbones, num_frames):
+                idx = temporal_subsample(frames.shape[0], max(num_frames), nf)  # video[:: max(num_frames) // nf]
+                video_values.append(vb.video_transform(frames[idx].contiguous()).unsqueeze(0))
+        else:  # merv.py:807-811
+            video_values = [torch.zeros(vb.default_video_resolution, device=dev).unsqueeze(0) for vb in self.video_backbones]
+        emb = self.llm_backbone.embed_input_ids(input_ids)
+        bos = 1 if getattr(self.llm_backbone.config, "bos_token_id", None) is not None else 0  # merv.py:521
+        fused_emb, _, _, weights = self.forward_visual(video_values, emb, bos_token_length=bos)
+        max_new = kwargs.pop("max_new_tokens", 32)
+        ids = self.llm_backbone.generate_from_embeds(fused_emb, max_new_tokens=max_new, do_sample=kwargs.pop("do_sample", False),
+                                                     temperature=kwargs.pop("temperature", 1.0),
+                                                     eos_token_id=getattr(self.llm_backbone.config, "eos_token_id", None))
+        self.last_fusion_weights = weights
+        if self.tokenizer is not None and hasattr(self.tokenizer, "decode"):
+            return self.tokenizer.decode(ids[0].tolist()).strip()
+        return ids

@@ -1,0 +1,62 @@
+"""GPU: the front door end to end -- pre-decoded clip -> frame indices -> per-encoder subsample -> GPU transforms -> HIP
+encoders -> projectors -> fusion -> splice -> LLM prefill + greedy decode (tiny random Llama, PyTorch-ROCm)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class ByteTokenizer:
+    def __call__(self, text):
+        return [1] + [3 + b for b in text.encode("utf-8")]
+
+    def decode(self, ids):
+        return bytes([max(0, min(255, i - 3)) for i in ids]).decode("latin-1")
+
+
+def _model(dev, ids, frames, tokenizer=None):
+    from merv_amd.backbones import VIDEO_BACKBONES
+    from merv_amd.llm import LlamaBackbone
+    from merv_amd.vidlm import MERV
+    bbs = [VIDEO_BACKBONES[i]["cls"](i, "resize-naive", num_frames=f, weights="random", device=dev, layers=1,
+                                     **VIDEO_BACKBONES[i]["kwargs"]) for i, f in zip(ids, frames)]
+    llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                             num_key_value_heads=4, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0),
+                        device=dev)
+    return MERV(bbs, llm, tokenizer=tokenizer, visual_feature_length=1024)
+
+
+def test_generate_merv_full_shape(dev):
+    ids = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-google-b-all-no-cls-16frames",
+           "siglip-vit-b16-224px-all-no-cls"]
+    m = _model(dev, ids, [16, 16, 32, 16], ByteTokenizer())
+    clip = (torch.randint(0, 256, (90, 120, 160, 3), dtype=torch.uint8), 29.97)  # decoded frames [N,H,W,3] + fps
+    pb = m.get_prompt_builder()
+    pb.add_turn("human", "What is happening?")
+    text = m.generate(clip, pb.get_prompt(), [16, 16, 32, 16], max_new_tokens=5)
+    assert isinstance(text, str)
+    w = m.last_fusion_weights
+    assert w.shape == (1, 4) and abs(float(w.sum()) - 1.0) < 1e-4
+    out_ids = m.generate(clip, [1, 5, 6, 7], [16, 16, 32, 16], max_new_tokens=5)  # deterministic greedy
+    again = m.generate(clip, [1, 5, 6, 7], [16, 16, 32, 16], max_new_tokens=5)
+    assert out_ids == again
+
+
+def test_generate_equals_manual_prefill(dev):
+    """generate() == embed -> splice fused tokens after BOS -> HF forward -> argmax, done by hand (config 1: DINOv2 only)."""
+    from merv_amd.sampler import temporal_subsample
+    from merv_amd.video_io import load_video
+    m = _model(dev, ["dinov2-video-all-tokens"], [4])
+    m.tokenizer = None
+    clip = (torch.randint(0, 256, (40, 3, 64, 80), dtype=torch.uint8), 25.0)
+    prompt = [1, 9, 8, 7, 6]
+    ids = m.generate(clip, prompt, [4], max_new_tokens=3)
+    assert ids.shape == (1, 3)
+    frames = load_video(clip, num_frames=4).to(dev)
+    pix = m.video_backbones[0].video_transform(frames[temporal_subsample(4, 4, 4)].contiguous())[None]
+    fused, _ = m.encode([pix])
+    emb = m.llm_backbone.embed_input_ids(torch.tensor([prompt], device=dev))
+    full = torch.cat([emb[:, :1], fused.to(emb.dtype), emb[:, 1:]], 1)
+    logits = m.llm_backbone.llm(inputs_embeds=full).logits[:, -1]
+    assert int(logits.argmax(-1)) == int(ids[0, 0])
+    assert fused.shape == (1, 256, 256)

@@ -139,3 +139,39 @@ def test_mervvisual_rejects_unsupported_arch():
         MERVVisual([FakeBB()], arch_specifier="gelu-mlp")
     with pytest.raises(ValueError):
         MERVVisual([FakeBB()], arch_specifier="avg+linear")
+
+
+def test_prompt_builders_match_reference_strings():
+    from merv_amd.prompting import LLaMa2ChatPromptBuilder, PurePromptBuilder
+    cases = json.loads((G / "prompts.json").read_text())  # produced by the reference's PurePromptBuilder
+    for c in cases:
+        pb = PurePromptBuilder("merv")
+        for t in c["turns"]:
+            assert pb.add_turn(t["role"], t["message"]) == t["wrapped"]
+        assert pb.get_prompt() == c["prompt"]
+        if c["potential"] is not None:
+            assert pb.get_potential_prompt("And then?") == c["potential"]
+    chat = LLaMa2ChatPromptBuilder("merv")
+    w = chat.add_turn("human", "<image>\nHi")
+    assert w.startswith("<s>[INST] <<SYS>\n") and w.endswith("Hi [/INST] ") and not chat.get_prompt().startswith("<s>")
+    with pytest.raises(AssertionError):
+        chat.add_turn("human", "again")  # roles must alternate
+
+
+def test_load_video_predecoded_and_gif(tmp_path):
+    import numpy as np
+    from PIL import Image
+    from merv_amd.video_io import load_video
+    cases = json.loads((G / "frame_indices.json").read_text())
+    c = next(c for c in cases if c["N"] == 300 and c["num_frames"] == 16)
+    frames = torch.arange(300, dtype=torch.uint8)[:, None, None, None].expand(300, 4, 6, 3).contiguous()  # frame i is filled with i % 256
+    out = load_video((frames, c["fps"]), clip_start_sec=c["clip_start_sec"], clip_end_sec=c["clip_end_sec"], num_frames=16)
+    assert out.shape == (16, 3, 4, 6) and out.dtype == torch.uint8
+    assert out[:, 0, 0, 0].tolist() == [i % 256 for i in c["ids"]]
+    imgs = [Image.fromarray(np.full((8, 10, 3), 20 * i, dtype=np.uint8)) for i in range(10)]
+    p = tmp_path / "clip.gif"
+    imgs[0].save(p, save_all=True, append_images=imgs[1:], duration=40, loop=0)
+    g = load_video(str(p), num_frames=4)
+    assert g.shape == (4, 3, 8, 10)
+    with pytest.raises(ImportError, match="decord"):
+        load_video(str(tmp_path / "missing.mp4"), num_frames=4)
