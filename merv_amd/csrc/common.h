@@ -44,7 +44,7 @@ MERV_DEVICE float activate(float x) {
         // erfc(-z) for z < 0, so the negative tail keeps its relative accuracy. One v_rcp + one v_exp + 6 FMAs.
         const float z = x * 0.70710678118654752440f;
         const float az = fabsf(z);
-        const float t = __frcp_rn(1.0f + 0.3275911f * az);
+        const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
         float poly = 1.061405429f;
         poly = poly * t - 1.453152027f;
         poly = poly * t + 1.421413741f;
@@ -63,6 +63,47 @@ MERV_DEVICE float activate(float x) {
     } else if constexpr (ACT == ACT_QUICK_GELU) {
         // CLIP quick_gelu: x * sigmoid(1.702 x)
         return x / (1.0f + __expf(-1.702f * x));
+    } else {
+        return x;
+    }
+}
+
+// Pair form of the activations for the GEMM epilogue: the fma / mul / add chains are written on 2-vectors so hipcc emits
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two values per issue slot); only the transcendentals are per element.
+// With all eight waves of a block in the epilogue at once the activation is pure VALU time with the matrix pipe idle:
+// measured 22-30 % of an fc1 launch before this form (tools/fc1_probe.py).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+template <int ACT>
+MERV_DEVICE f32x2 activate2(f32x2 x) {
+    if constexpr (ACT == ACT_GELU_ERF) {
+        // gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - 0.5 |x| erfc(|x|/sqrt2); erfc by A&S 7.1.26 (|err| <= 1.5e-7):
+        // erfc(z) = (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + 0.3275911 z). No compare / select, relative accuracy
+        // kept on the negative tail. Coefficients carry the factor 0.5.
+        const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+        const f32x2 d = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
+        const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        f32x2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
+        p = p * t + (0.5f * 1.421413741f);
+        p = p * t + (0.5f * -0.284496736f);
+        p = p * t + (0.5f * 0.254829592f);
+        p = p * t;
+        const f32x2 u = (x * x) * (-0.5f * 1.4426950408889634f);  // -z^2 log2(e)
+        const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+        const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+        return r - (ax * p) * e;
+    } else if constexpr (ACT == ACT_GELU_TANH) {
+        // 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + exp(-2u)),  u = 0.7978845608 x (1 + 0.044715 x^2)
+        const f32x2 q = (x * x) * 0.044715f + 1.0f;
+        const f32x2 a = (x * q) * (-2.0f * 0.7978845608f * 1.4426950408889634f);  // -2u log2(e)
+        const f32x2 d = {__builtin_amdgcn_exp2f(a[0]) + 1.0f, __builtin_amdgcn_exp2f(a[1]) + 1.0f};
+        const f32x2 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return x * rc;
+    } else if constexpr (ACT == ACT_QUICK_GELU) {
+        const f32x2 a = x * (-1.702f * 1.4426950408889634f);
+        const f32x2 d = {__builtin_amdgcn_exp2f(a[0]) + 1.0f, __builtin_amdgcn_exp2f(a[1]) + 1.0f};
+        const f32x2 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        return x * rc;
     } else {
         return x;
     }

@@ -112,9 +112,11 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM / 1
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const f32x4 v = acc[i][j];
+            const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
+            const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
             u32x2 o;
-            o[0] = pack2bf(activate<ACT>(v[0] + bias4[i].x) * ls4[i].x, activate<ACT>(v[1] + bias4[i].y) * ls4[i].y);
-            o[1] = pack2bf(activate<ACT>(v[2] + bias4[i].z) * ls4[i].z, activate<ACT>(v[3] + bias4[i].w) * ls4[i].w);
+            o[0] = pack2bf(lo[0], lo[1]);
+            o[1] = pack2bf(hi[0], hi[1]);
             const int row = j * 16 + frow;
             const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
             *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
