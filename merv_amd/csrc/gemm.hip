@@ -179,11 +179,29 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     const int tn = in_grp / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    // Per-lane DMA source pointers of this thread's pieces at kt = 0 (row clamp and source swizzle folded in once):
+    // a K-step then costs one 64-bit add per piece instead of the whole address computation.
+    const bf16_t* a_src[A_PIECES];
+    const bf16_t* w_src[W_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        int grow = m0 + row;
+        grow = grow < p.M - 1 ? grow : p.M - 1;  // out-of-range rows re-read the last valid row
+        a_src[i] = p.A + (size_t)grow * p.lda + (((lane & 7) ^ (row & 7)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < W_PIECES; ++i) {
+        const int row = (i * NW + wave) * 8 + (lane >> 3);
+        w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + (((lane & 7) ^ (row & 7)) * 8);
+    }
     // piece `pc` (0..DPS-1) of tile kt into stage `buf`
     auto dma_piece = [&](int kt, int buf, int pc) {
         char* a_tile = smem + buf * STAGE_BYTES;
-        if (pc < A_PIECES) dma_rows8(p.A, p.lda, m0, p.M - 1, pc * NW + wave, kt * BK, a_tile, lane);
-        else dma_rows8(p.W, p.ldw, n0, p.N - 1, (pc - A_PIECES) * NW + wave, kt * BK, a_tile + A_BYTES, lane);
+        const bf16_t* src = pc < A_PIECES ? a_src[pc < A_PIECES ? pc : 0] : w_src[pc >= A_PIECES ? pc - A_PIECES : 0];
+        char* dst = pc < A_PIECES ? a_tile + (pc * NW + wave) * 1024 : a_tile + A_BYTES + ((pc - A_PIECES) * NW + wave) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + kt * BK),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
 
     f32x4 acc[NI][MI];
