@@ -135,14 +135,46 @@ class MERV(MERVVisual):
     `tokenizer` is any callable object with `__call__(text) -> list[int]` (incl. BOS) and `decode(ids) -> str`; HF
     tokenizers are adapted by `HFTokenizerAdapter`. (The Llama tokenizer files cannot be fetched here.)"""
 
-    def __init__(self, video_backbones, llm_backbone, tokenizer=None, **kw) -> None:
+    model_family = "merv"
+
+    def __init__(self, video_backbones, llm_backbone, tokenizer=None, model_id: str = "merv", **kw) -> None:
         super().__init__(video_backbones, llm_dim=llm_backbone.embed_dim, **kw)
+        self.model_id = model_id
         self.llm_backbone = llm_backbone
         self.tokenizer = tokenizer
 
-    def get_prompt_builder(self, system_prompt=None, chat: bool = False):
+    @classmethod
+    def from_pretrained(cls, pretrained_checkpoint, model_id: str, video_backbones, llm_backbone,
+                        enable_mixed_precision_training: bool = True, arch_specifier: str = "3davg+linear",
+                        feature_fusion: Optional[str] = None, visual_feature_length: Optional[int] = -1,
+                        projector_token_length: Optional[int] = -1, tokenizer=None) -> "MERV":
+        """merv.py:246-299: build, then load `projectors`, `llm_backbone` and `feature_fusion` (or legacy `adapter`) from
+        the checkpoint's "model" dict; everything frozen, eval mode."""
+        vidlm = cls(video_backbones, llm_backbone, tokenizer=tokenizer, model_id=model_id, arch_specifier=arch_specifier,
+                    feature_fusion=feature_fusion, visual_feature_length=visual_feature_length,
+                    projector_token_length=projector_token_length)
+        model_state_dict = torch.load(pretrained_checkpoint, map_location="cpu", weights_only=True)["model"]
+        if "projector" in model_state_dict:
+            model_state_dict["projectors"] = {"0." + k: v for k, v in model_state_dict["projector"].items()}
+        assert "projectors" in model_state_dict and "llm_backbone" in model_state_dict, (
+            "MERV `from_pretrained` expects checkpoint with keys for `projector` AND `llm_backbone`!"
+            + f'{("projectors" in model_state_dict, "llm_backbone" in model_state_dict)}')
+        if vidlm.feature_fusion is None:
+            assert "feature_fusion" not in model_state_dict or len(model_state_dict["feature_fusion"]) == 0, \
+                model_state_dict["feature_fusion"]
+        vidlm.load_from_checkpoint_dict(model_state_dict)
+        vidlm.llm_backbone.load_state_dict(model_state_dict["llm_backbone"])
+        vidlm.to(llm_backbone.device)
+        vidlm.requires_grad_(False)
+        vidlm.eval()
+        return vidlm
+
+    def get_prompt_builder(self, system_prompt=None, chat: Optional[bool] = None):
+        """merv.py:832-835: the LLM backbone picks the builder; `chat` is kept as an explicit override."""
         from .prompting import LLaMa2ChatPromptBuilder, PurePromptBuilder
-        return (LLaMa2ChatPromptBuilder if chat else PurePromptBuilder)("merv", system_prompt=system_prompt)
+        if chat is None and hasattr(self.llm_backbone, "prompt_builder_fn"):
+            return self.llm_backbone.prompt_builder_fn(self.model_family, system_prompt=system_prompt)
+        return (LLaMa2ChatPromptBuilder if chat else PurePromptBuilder)(self.model_family, system_prompt=system_prompt)
 
     @torch.inference_mode()
     def generate(self, video, prompt_text, num_frames, **kwargs):

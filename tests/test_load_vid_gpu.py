@@ -1,0 +1,94 @@
+"""GPU: `load_vid()` on a run directory laid out like the reference's (config.json + checkpoints/latest-checkpoint.pt,
+load_vid.py:46-127), BASELINE.json configs[0]: the DINOv2-only single-encoder registry model on 4 frames with greedy
+decode. Encoder parameters are read from a timm-layout state-dict file; the LLM is a reduced-geometry Llama."""
+import json
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TINY_LLM = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=4, max_position_embeddings=2048, rms_norm_eps=1e-5, bos_token_id=1, eos_token_id=2,
+                pad_token_id=0)
+
+
+def _write_run(tmp_path, dev):
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import EncoderSpec
+    from merv_amd.llm import LlamaBackbone
+    from merv_amd.projector import AveragePooling3DProjector
+    from merv_amd.weights import to_timm_names
+    run = tmp_path / "dinov2-single+4f"
+    (run / "checkpoints").mkdir(parents=True)
+    (run / "encoders").mkdir()
+    cfg = {"model": {"type": "dinov2-single", "vidlm_id": None, "model_id": "dinov2-single",
+                     "arch_specifier": "no-align+3davg+linear", "feature_fusion": None,
+                     "video_backbone_ids": ["dinov2-video-all-tokens"], "llm_backbone_id": "llama2-7b-pure",
+                     "image_resize_strategy": "resize-naive", "llm_max_length": 2048, "num_frames": 4,
+                     "projector_token_length": 64, "visual_feature_length": 1024}}
+    cfg["model"].pop("vidlm_id")
+    (run / "config.json").write_text(json.dumps(cfg))
+    spec = EncoderSpec("dinov2", 1024, 16, 4096, 23, 14, 1, 224, 4, "BFCHW", 5, False, False, False, True, 0, "gelu_erf", 1e-6)
+    canon = random_weights(spec, seed=7)
+    torch.save(to_timm_names(canon), run / "encoders" / "dinov2-video-all-tokens.pt")
+    torch.manual_seed(3)
+    proj = AveragePooling3DProjector(1024, 256, output_frames=4, output_size=8, mlp_type="linear")
+    llm = LlamaBackbone(TINY_LLM, device="cpu", seed=5)
+    ckpt = {"model": {"projector": {k: v.clone() for k, v in proj.state_dict().items()},  # legacy single-projector key, merv.py:273
+                      "llm_backbone": {k: v.clone() for k, v in llm.state_dict().items()}}}
+    torch.save(ckpt, run / "checkpoints" / "latest-checkpoint.pt")
+    return run, spec, canon, proj, llm
+
+
+def test_load_vid_config0_dinov2_single_greedy(tmp_path, dev):
+    from oracle import merv_oracle as O
+    from merv_amd.load import available_models, load_vid
+    assert "dinov2-single" in available_models()
+    run, spec, canon, proj, llm_cpu = _write_run(tmp_path, dev)
+    vidlm, cfg = load_vid(run, get_model_cfg=True, llm_config=TINY_LLM, device=dev)
+    assert cfg["num_frames"] == [4] and cfg["model_id"] == "dinov2-single"
+    assert vidlm.visual_feature_length == 256 and vidlm.feature_fusion is None
+    assert type(vidlm.get_prompt_builder()).__name__ == "PurePromptBuilder"
+    g = torch.Generator().manual_seed(0)
+    frames = torch.randint(0, 256, (4, 3, 240, 320), generator=g, dtype=torch.uint8)
+    prompt_ids = [1, 17, 44, 9, 201]
+    ids = vidlm.generate((frames, 30.0), prompt_ids, [4], max_new_tokens=6)
+    assert ids.shape[0] == 1 and 1 <= ids.shape[1] <= 6
+    # (1) the loaded visual branch against the oracle on the same pixels and parameters
+    pix = vidlm.video_backbones[0].video_transform(frames.to(dev)).unsqueeze(0)
+    fused, w = vidlm.encode([pix])
+    assert w is None and fused.shape == (1, 256, 256)
+    ocfg = O.EncoderCfg(**{k: getattr(spec, k) for k in O.EncoderCfg.__dataclass_fields__})
+    tok = O.encoder_forward(pix.float().cpu(), ocfg, canon)
+    lin = proj.projector.projector
+    ref = O.projector_forward(tok, 4, 16, 8, lin.weight.detach(), lin.bias.detach())
+    assert rel_l2(fused, ref) < 2e-2
+    # (2) the decode loop against a plain greedy loop on the CPU copy of the same LLM over the same embeddings
+    emb = vidlm.llm_backbone.embed_input_ids(torch.tensor([prompt_ids], device=dev))
+    full, _, _, _ = vidlm.forward_visual([pix], emb)
+    x = full.float().cpu()
+    ref_llm = llm_cpu.llm.float()
+    emb_w = ref_llm.get_input_embeddings().weight
+    greedy = []
+    for _ in range(ids.shape[1]):
+        nxt = int(ref_llm(inputs_embeds=x).logits[0, -1].argmax())
+        greedy.append(nxt)
+        x = torch.cat([x, emb_w[nxt][None, None]], 1)
+    assert greedy[0] == int(ids[0, 0])  # later tokens may legitimately flip on bf16 near-ties
+    agree = sum(int(a == b) for a, b in zip(greedy, ids[0].tolist()))
+    assert agree >= ids.shape[1] - 2, (greedy, ids)
+
+
+def test_load_vid_errors(tmp_path, dev):
+    from merv_amd.load import load_vid
+    with pytest.raises(ValueError):
+        load_vid("no-such-model")
+    with pytest.raises(FileNotFoundError):
+        load_vid("merv-full", cache_dir=tmp_path)  # registry id, nothing on disk, no hub
+    run, *_ = _write_run(tmp_path, dev)
+    (run / "encoders" / "dinov2-video-all-tokens.pt").unlink()
+    with pytest.raises(FileNotFoundError):
+        load_vid(run, llm_config=TINY_LLM, device=dev)  # never a silent random encoder

@@ -300,6 +300,32 @@ def gen_prompts():
                       "potential": pb.get_potential_prompt("And then?") if len(turns) % 2 == 0 else None})
     (OUT / "prompts.json").write_text(json.dumps(cases, indent=1))
     print("prompts: ok", cases[0]["prompt"])
+    # chat builders: their files import the base class through the absolute package path
+    chain = "merv.models.backbones.llm.prompting.base_prompter".split(".")
+    for i in range(1, len(chain)):
+        name = ".".join(chain[:i])
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    sys.modules[".".join(chain)] = bp
+    chat_cases = []
+    for fname, cls in (("llama2_chat_prompter.py", "LLaMa2ChatPromptBuilder"), ("vicuna_v15_prompter.py", "VicunaV15ChatPromptBuilder")):
+        mod = _load("ref_prompting." + fname[:-3], base / fname, package="ref_prompting")
+        for sysprompt in (None, "Answer briefly."):
+            for turns in (["<image>\nWhat is happening in this video?"], ["Describe the video.", "A cat jumps.", "What colour is it?"],
+                          ["Q1", "", "Q2", "A2"]):
+                pb = getattr(mod, cls)("merv", system_prompt=sysprompt)
+                first_potential = pb.get_potential_prompt("And then?")
+                seq = []
+                for i, msg in enumerate(turns):
+                    role = "human" if i % 2 == 0 else "gpt"
+                    seq.append({"role": role, "message": msg, "wrapped": pb.add_turn(role, msg)})
+                chat_cases.append({"builder": cls, "system_prompt": sysprompt, "turns": seq, "prompt": pb.get_prompt(),
+                                   "first_potential": first_potential,
+                                   "potential": pb.get_potential_prompt("And then?") if len(turns) % 2 == 0 else None})
+    (OUT / "prompts_chat.json").write_text(json.dumps(chat_cases, indent=1))
+    print("prompts_chat: ok", len(chat_cases))
 
 
 if __name__ == "__main__":
