@@ -140,7 +140,40 @@ int merv_fusion_forward(const void *const *v, int32_t num_encoders, int32_t batc
 int merv_splice_forward(const void *emb, const void *vis, int32_t batch, int32_t S, int32_t T, int32_t C,
                         int32_t bos, void *out, void *stream);
 
+/*
+ * ---- backward of the trainable tail ----
+ * What torch autograd computes for the reference under loss.backward() (merv/training/strategies/base_strategy.py,
+ * the `normalized_loss.backward()` of run_training) through CrossAttentionAdapterLearnableQuery.forward
+ * (merv/util/nn_utils.py:487-521) and AveragePooling3DProjector.forward (nn_utils.py:320-330). The encoders are
+ * frozen (merv.py:562), so no gradient flows past the pooled encoder tokens.
+ *
+ * Fusion: out = sum_e w_e V_e, w = softmax_e(mean_t(V_e) . u).
+ *   merv_fusion_backward_reduce: dw[b,e] = sum_{t,c} grad_out[b,t,c] V_e[b,t,c] and vbar[b,e,:] = mean_t V_e (fp32).
+ *     The binding then forms ds = w * (dw - sum_e w dw) and du = sum_{b,e} ds[b,e] vbar[b,e,:] (B x E scalars).
+ *   merv_fusion_backward_mix:    dV_e = w_e grad_out + (ds_e / T) u, bf16, one tensor per encoder.
+ * ws: merv_fusion_backward_workspace_floats(B,E,T,C) floats.
+ */
+size_t merv_fusion_backward_workspace_floats(int32_t batch, int32_t num_encoders, int32_t T, int32_t C);
+int merv_fusion_backward_reduce(const void *const *v, int32_t num_encoders, int32_t batch, int32_t T, int32_t C,
+                                const void *grad_out, float *ws, float *dw_out, float *vbar_out, void *stream);
+int merv_fusion_backward_mix(const void *grad_out, const float *weights, const float *ds, const float *u,
+                             int32_t num_encoders, int32_t batch, int32_t T, int32_t C, void *const *dv_out,
+                             void *stream);
+
+/*
+ * Projector: Y = pooled W^T + b with pooled [M, C] (the `pooled_ws` buffer merv_projector_forward filled), Y [M, llm].
+ *   grad_w [llm, C] bf16 = grad_out^T pooled  (two transposes + the forward GEMM kernel, fp32 accumulation over M)
+ *   grad_b [llm] fp32    = column sums of grad_out
+ * C % 128 == 0, llm % 8 == 0. ws: merv_projector_backward_workspace_bytes(M, C, llm) bytes, 256-byte aligned.
+ */
+size_t merv_projector_backward_workspace_bytes(int32_t M, int32_t C, int32_t llm_dim);
+int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M, int32_t C, int32_t llm_dim,
+                            void *ws, size_t ws_bytes, void *grad_w, float *grad_b, void *stream);
+
 /* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
+/* out[c][r] = in[r][c] (bf16), columns R..Rpad-1 of `out` zero-filled; ldi, ldo, Rpad even. */
+int merv_transpose_bf16(const void *in, int32_t R, int32_t C, int32_t ldi, void *out, int32_t ldo, int32_t Rpad,
+                        void *stream);
 int merv_gemm_bf16(const void *A, const void *W, void *C, const float *bias, const float *lscale, const void *res,
                    int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc, int32_t ldres,
                    int32_t res_row_mod, int32_t out_group, int32_t out_stride, int32_t out_off, int32_t act,

@@ -281,6 +281,90 @@ extern "C" int merv_splice_forward(const void* emb, const void* vis, int32_t bat
     return 0;
 }
 
+// ---- backward of the trainable tail (row f-4) ----
+extern "C" size_t merv_fusion_backward_workspace_floats(int32_t batch, int32_t E, int32_t T, int32_t C) {
+    if (batch <= 0 || E <= 0 || T <= 0 || C <= 0) return 0;
+    return fusion_bwd_workspace_floats(batch, E, T, C);
+}
+
+extern "C" int merv_fusion_backward_reduce(const void* const* v, int32_t E, int32_t batch, int32_t T, int32_t C,
+                                           const void* grad_out, float* ws, float* dw_out, float* vbar_out, void* stream_) {
+    MERV_CHECK(v && grad_out && ws && dw_out && vbar_out, "merv_fusion_backward_reduce: null argument");
+    MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_backward_reduce: 1..8 encoders supported");
+    MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_backward_reduce: bad geometry");
+    FusionBwdArgs a;
+    memset(&a, 0, sizeof a);
+    for (int e = 0; e < E; ++e) {
+        MERV_CHECK(v[e], "merv_fusion_backward_reduce: null encoder tensor");
+        a.v[e] = (const bf16_t*)v[e];
+    }
+    a.grad_out = (const bf16_t*)grad_out;
+    a.E = E; a.B = batch; a.T = T; a.C = C; a.dw = dw_out; a.vbar = vbar_out;
+    MERV_HIP(launch_fusion_bwd_reduce(a, ws, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_fusion_backward_mix(const void* grad_out, const float* weights, const float* ds, const float* u,
+                                        int32_t E, int32_t batch, int32_t T, int32_t C, void* const* dv_out, void* stream_) {
+    MERV_CHECK(grad_out && weights && ds && u && dv_out, "merv_fusion_backward_mix: null argument");
+    MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_backward_mix: 1..8 encoders supported");
+    MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_backward_mix: bad geometry");
+    FusionBwdMixArgs a;
+    memset(&a, 0, sizeof a);
+    for (int e = 0; e < E; ++e) {
+        MERV_CHECK(dv_out[e], "merv_fusion_backward_mix: null output tensor");
+        a.dv[e] = (bf16_t*)dv_out[e];
+    }
+    a.grad_out = (const bf16_t*)grad_out; a.w = weights; a.ds = ds; a.u = u;
+    a.E = E; a.B = batch; a.T = T; a.C = C;
+    MERV_HIP(launch_fusion_bwd_mix(a, (hipStream_t)stream_));
+    return 0;
+}
+
+static inline int pad64(int v) { return (v + 63) / 64 * 64; }
+
+extern "C" size_t merv_projector_backward_workspace_bytes(int32_t M, int32_t C, int32_t llm) {
+    if (M <= 0 || C <= 0 || llm <= 0) return 0;
+    const size_t mp = (size_t)pad64(M);
+    return align_up((size_t)llm * mp * 2, 256) + align_up((size_t)C * mp * 2, 256) + align_up(colsum_workspace_floats(llm) * 4, 256);
+}
+
+extern "C" int merv_projector_backward(const void* grad_out, const void* pooled, int32_t M, int32_t C, int32_t llm, void* ws,
+                                       size_t ws_bytes, void* grad_w, float* grad_b, void* stream_) {
+    MERV_CHECK(grad_out && pooled && ws && grad_w && grad_b, "merv_projector_backward: null argument");
+    MERV_CHECK(M > 0 && C > 0 && C % 128 == 0 && llm > 0 && llm % 8 == 0, "merv_projector_backward: need C % 128 == 0, llm % 8 == 0");
+    MERV_CHECK(ws_bytes >= merv_projector_backward_workspace_bytes(M, C, llm), "merv_projector_backward: workspace too small");
+    MERV_CHECK(((uintptr_t)ws & 255) == 0, "merv_projector_backward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    const int mp = pad64(M);
+    char* base = (char*)ws;
+    bf16_t* gT = (bf16_t*)base;                                   // [llm, mp]
+    bf16_t* pT = (bf16_t*)(base + align_up((size_t)llm * mp * 2, 256));  // [C, mp]
+    float* cs = (float*)((char*)pT + align_up((size_t)C * mp * 2, 256));
+    TransposeArgs tg{(const bf16_t*)grad_out, gT, M, llm, llm, mp, mp};
+    MERV_HIP(launch_transpose(tg, s));
+    TransposeArgs tp{(const bf16_t*)pooled, pT, M, C, C, mp, mp};
+    MERV_HIP(launch_transpose(tp, s));
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = gT; g.W = pT; g.C = (bf16_t*)grad_w;
+    g.M = llm; g.N = C; g.K = mp; g.lda = mp; g.ldw = mp; g.ldc = C; g.act = ACT_NONE;
+    MERV_HIP(launch_gemm(g, s));
+    ColsumArgs c{(const bf16_t*)grad_out, cs, grad_b, M, llm, llm};
+    MERV_HIP(launch_colsum(c, s));
+    return 0;
+}
+
+extern "C" int merv_transpose_bf16(const void* in, int32_t R, int32_t C, int32_t ldi, void* out, int32_t ldo, int32_t Rpad,
+                                   void* stream_) {
+    MERV_CHECK(in && out, "merv_transpose_bf16: null argument");
+    MERV_CHECK(R > 0 && C > 0 && Rpad >= R && Rpad % 2 == 0 && ldi % 2 == 0 && ldo % 2 == 0 && ldi >= C && ldo >= Rpad,
+               "merv_transpose_bf16: bad geometry (ldi, ldo, Rpad even; ldi >= C; ldo >= Rpad >= R)");
+    TransposeArgs t{(const bf16_t*)in, (bf16_t*)out, R, C, ldi, ldo, Rpad};
+    MERV_HIP(launch_transpose(t, (hipStream_t)stream_));
+    return 0;
+}
+
 // ---- frame preprocessing (row a3) ----
 extern "C" size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t out_size) {
     if (T <= 0 || H <= 0 || W <= 0 || out_size <= 0) return 0;

@@ -110,6 +110,45 @@ struct FusionArgs {
 hipError_t launch_fusion(const FusionArgs& a, hipStream_t s);
 int fusion_partial_floats(int B, int E, int T);
 
+// ---- backward of the trainable tail (backward.hip) ----
+struct FusionBwdArgs {
+    const bf16_t* v[8];      // E tensors [B, T, C] (the forward inputs)
+    const bf16_t* grad_out;  // [B, T, C]
+    int E, B, T, C;
+    float* partial_vs;       // workspace, set by the launcher
+    float* partial_dw;       // workspace, set by the launcher
+    float* dw;               // [B, E] out: sum_{t,c} grad_out * V_e
+    float* vbar;             // [B, E, C] out: mean_t V_e
+};
+size_t fusion_bwd_workspace_floats(int B, int E, int T, int C);
+hipError_t launch_fusion_bwd_reduce(FusionBwdArgs a, float* ws, hipStream_t s);
+
+struct FusionBwdMixArgs {
+    const bf16_t* grad_out;  // [B, T, C]
+    const float* w;          // [B, E] forward softmax weights
+    const float* ds;         // [B, E] gradient w.r.t. the scores
+    const float* u;          // [C]
+    bf16_t* dv[8];           // E outputs [B, T, C]
+    int E, B, T, C;
+};
+hipError_t launch_fusion_bwd_mix(const FusionBwdMixArgs& a, hipStream_t s);
+
+struct TransposeArgs {
+    const bf16_t* in;  // [R, C], leading dim ldi
+    bf16_t* out;       // [C, Rpad], leading dim ldo; columns R..Rpad-1 are zero-filled
+    int R, C, ldi, ldo, Rpad;
+};
+hipError_t launch_transpose(const TransposeArgs& a, hipStream_t s);
+
+struct ColsumArgs {
+    const bf16_t* x;  // [M, N], leading dim ld
+    float* partial;   // workspace [colsum_workspace_floats(N)]
+    float* out;       // [N]
+    int M, N, ld;
+};
+size_t colsum_workspace_floats(int N);
+hipError_t launch_colsum(const ColsumArgs& a, hipStream_t s);
+
 // Splice fused visual tokens after the BOS embedding (merv.py:633-640):
 // out[b] = cat(emb[b, :bos], vis[b], emb[b, bos:]).
 struct SpliceArgs {

@@ -321,6 +321,46 @@ def splice(input_embeddings: torch.Tensor, fused: torch.Tensor, bos_token_length
 
 
 # ------------------------------------------------------------------------------------------------------------
+# f-4. training-mode batch assembly and loss -- merv/models/vidlms/merv.py:612-734 (unpinned: MERV.forward cannot be
+# imported here; restated line by line). Gradients of the projector / fusion parameters are torch autograd through
+# projector_forward / fusion_forward above, exactly what the reference's loss.backward() differentiates.
+# ------------------------------------------------------------------------------------------------------------
+def assemble_training_batch(input_embeddings: torch.Tensor, fused: torch.Tensor, attention_mask: torch.Tensor,
+                            labels: torch.Tensor, multimodal_indices: torch.Tensor, bos_token_length: int = 1,
+                            ignore_index: int = -100):
+    """Multimodal rows: visual span after BOS, mask True, labels IGNORE (:633-664). Unimodal rows: padded at the end by
+    `padcount` spans of zeros / False / IGNORE (:676-713), stacked under the multimodal rows (:716-719)."""
+    mm = multimodal_indices
+    emb_mm, am_mm, lab_mm = splice(input_embeddings[mm], fused, bos_token_length, attention_mask[mm], labels[mm], ignore_index)
+    uni = torch.tensor([i for i in range(input_embeddings.shape[0]) if i not in set(mm.tolist())], dtype=torch.long)
+    if len(uni) == 0:
+        return emb_mm, am_mm, lab_mm
+    Tv = fused.shape[1]
+    padcount = (emb_mm.shape[1] - input_embeddings.shape[1]) // Tv  # == 1
+    emb_u = torch.cat([input_embeddings[uni]] + [torch.zeros(len(uni), Tv, input_embeddings.shape[2])] * padcount, dim=1)
+    am_u = torch.cat([attention_mask[uni]] + [torch.full((len(uni), Tv), False, dtype=attention_mask.dtype)] * padcount, dim=1)
+    lab_u = torch.cat([labels[uni]] + [torch.full((len(uni), Tv), ignore_index, dtype=labels.dtype)] * padcount, dim=1)
+    return torch.vstack([emb_mm, emb_u]), torch.vstack([am_mm, am_u]), torch.vstack([lab_mm, lab_u])
+
+
+def causal_lm_loss(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100) -> torch.Tensor:
+    """The HF causal-LM loss the reference returns (llm_backbone(..., labels=...), merv.py:723-734): token t predicts
+    label t+1, mean cross-entropy over the labels that are not IGNORE_INDEX."""
+    shift_logits = logits[:, :-1].reshape(-1, logits.shape[-1]).float()
+    shift_labels = labels[:, 1:].reshape(-1)
+    return F.cross_entropy(shift_logits, shift_labels, ignore_index=ignore_index)
+
+
+def cosine_schedule_with_warmup(step: int, num_warmup_steps: int, num_training_steps: int) -> float:
+    """LR multiplier of transformers.get_cosine_schedule_with_warmup (num_cycles = 0.5), the scheduler the reference
+    builds (training/strategies/fsdp.py:291)."""
+    if step < num_warmup_steps:
+        return step / max(1, num_warmup_steps)
+    progress = (step - num_warmup_steps) / max(1, num_training_steps - num_warmup_steps)
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+
+
+# ------------------------------------------------------------------------------------------------------------
 # whole path: a4-a10 (merv.py:562-609)
 # ------------------------------------------------------------------------------------------------------------
 def visual_path_forward(pixels: Sequence[torch.Tensor], cfgs: Sequence[EncoderCfg], enc_W: Sequence[Dict],

@@ -235,3 +235,49 @@ def test_llm_registry_families_and_prompt_builders():
     assert LLM_BACKBONES["mistral-v0.2-7b-instruct"][1]()["num_key_value_heads"] == 8
     with pytest.raises(ValueError):
         get_llm_backbone_and_tokenizer("gpt-17")
+
+
+def test_training_schedule_and_optimizer_groups():
+    from transformers import get_cosine_schedule_with_warmup
+    from oracle import merv_oracle as O
+    from merv_amd.train import build_optimizer, cosine_with_warmup
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    sch = get_cosine_schedule_with_warmup(opt, 3, 40)  # the scheduler the reference builds, fsdp.py:291
+    for s in range(45):
+        want = opt.param_groups[0]["lr"]
+        assert abs(cosine_with_warmup(s, 3, 40) - want) < 1e-12 and abs(O.cosine_schedule_with_warmup(s, 3, 40) - want) < 1e-12
+        opt.step()
+        sch.step()
+    lin = torch.nn.Linear(4, 3)
+    ln = torch.nn.LayerNorm(3)
+    named = [("projectors.0.projector.projector.weight", lin.weight), ("projectors.0.projector.projector.bias", lin.bias),
+             ("llm.norm.weight", ln.weight), ("feature_fusion.Q", torch.nn.Parameter(torch.zeros(1, 8)))]
+    o = build_optimizer(named, 1e-3, 0.1)
+    decay, no_decay = o.param_groups
+    assert decay["weight_decay"] == 0.1 and no_decay["weight_decay"] == 0.0
+    assert [p.shape for p in decay["params"]] == [lin.weight.shape, (1, 8)]  # ndim <= 1 or *.bias are not decayed (fsdp.py:281-286)
+    assert [p.shape for p in no_decay["params"]] == [lin.bias.shape, ln.weight.shape]
+
+
+def test_oracle_training_batch_assembly_layout():
+    from oracle import merv_oracle as O
+    B, S, Cc, Tv = 4, 6, 8, 5
+    emb = torch.arange(B * S * Cc, dtype=torch.float32).reshape(B, S, Cc)
+    fused = -torch.ones(2, Tv, Cc)
+    am = torch.ones(B, S, dtype=torch.bool)
+    am[3, 4:] = False
+    lab = torch.arange(B * S).reshape(B, S)
+    mm = torch.tensor([0, 2])
+    e, a, l = O.assemble_training_batch(emb, fused, am, lab, mm, 1)
+    assert e.shape == (4, S + Tv, Cc) and a.shape == l.shape == (4, S + Tv)
+    # multimodal rows first (in multimodal_indices order): [BOS | visual | rest]
+    assert torch.equal(e[1, 0], emb[2, 0]) and torch.equal(e[1, 1:1 + Tv], fused[1]) and torch.equal(e[1, 1 + Tv:], emb[2, 1:])
+    assert bool(a[0, 1:1 + Tv].all()) and bool((l[0, 1:1 + Tv] == -100).all()) and l[0, 0] == lab[0, 0]
+    # unimodal rows below, padded at the END (merv.py:686-713)
+    assert torch.equal(e[2, :S], emb[1]) and not e[2, S:].any() and not a[2, S:].any() and bool((l[2, S:] == -100).all())
+    assert torch.equal(a[3, :S], am[3]) and torch.equal(l[3, :S], lab[3])
+    logits = torch.randn(4, S + Tv, 11)
+    labels = torch.randint(0, 11, (4, S + Tv))
+    labels[:, :3] = -100
+    want = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, 11), labels[:, 1:].reshape(-1), ignore_index=-100)
+    assert torch.allclose(O.causal_lm_loss(logits, labels), want)
