@@ -43,9 +43,12 @@ MERV_DEVICE void dma_rows8(const bf16_t* __restrict__ g, int ld, int row0, int r
 }
 
 // ---- epilogue (shared by all tile configurations) ----
-template <int WTM, int WTN, bool REMAP, int ACT>
-MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM / 16], char* smem, int wave, int lane, int m0,
+template <int WTM_FULL, int WTN, bool REMAP, int ACT, int MSPLIT = 1>
+MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FULL / 16], char* smem, int wave, int lane, int m0,
                                int n0, int wr, int wc) {
+    // MSPLIT > 1: the wave's rows are finished in MSPLIT passes of WTM rows each (bounds the registers the residual
+    // rows and offsets take next to a 128-register accumulator)
+    constexpr int WTM = WTM_FULL / MSPLIT;
     constexpr int MI = WTM / 16, NI = WTN / 16;
     const int frow = lane & 15, fq = lane >> 4;
     // The accumulators hold D^T fragments (4 consecutive n per lane, 32-byte row segments per instruction): stored
@@ -57,38 +60,11 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM / 1
     static_assert(WTN == 64, "epilogue staging assumes 64-column wave tiles");
     constexpr int EP_IT = WTM / 8;  // 16-byte chunks per lane: WTM rows x 8 chunks / 64 lanes
     const int wn0 = n0 + wc * WTN;
-    uint32_t c_off[EP_IT];  // element offsets (the launcher checks they fit 32 bits)
-    bool valid[EP_IT];
-    u32x4 resv[EP_IT];
     // opaque copy of the lane id: keeps the compiler from hoisting the epilogue's index arithmetic (integer
     // divisions) above the K-loop, where it would sit in registers -- or scratch -- for the whole kernel
     int elane = lane;
     asm volatile("" : "+v"(elane));
     const int ec = elane & 7;  // this lane's 16-byte chunk (8 columns) of each row it handles
-    uint32_t r_off[EP_IT];
-#pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-        const int r = (elane >> 3) + 8 * it;
-        const int m = m0 + wr * WTM + r;
-        valid[it] = m < p.M;
-        const int mc = valid[it] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
-        int orow = mc, rr = mc;
-        if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
-            if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
-            if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
-        }
-        c_off[it] = (uint32_t)orow * (uint32_t)p.ldc + wn0 + ec * 8;
-        r_off[it] = (uint32_t)rr * (uint32_t)p.ldres + wn0 + ec * 8;
-    }
-    // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
-    // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
-    if (p.res) {
-#pragma unroll
-        for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
-    } else {
-#pragma unroll
-        for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
-    }
     float4 bias4[NI], ls4[NI];
     if (p.bias) {
 #pragma unroll
@@ -104,35 +80,66 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM / 1
 #pragma unroll
         for (int i = 0; i < NI; ++i) ls4[i] = float4{1.f, 1.f, 1.f, 1.f};
     }
-    // every wave is done with the stage ring
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int part = 0; part < MSPLIT; ++part) {
+        uint32_t c_off[EP_IT];  // element offsets (the launcher checks they fit 32 bits)
+        bool valid[EP_IT];
+        u32x4 resv[EP_IT];
+        uint32_t r_off[EP_IT];
 #pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            const f32x4 v = acc[i][j];
-            const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
-            const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
-            u32x2 o;
-            o[0] = pack2bf(lo[0], lo[1]);
-            o[1] = pack2bf(hi[0], hi[1]);
-            const int row = j * 16 + frow;
-            const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
-            *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
+        for (int it = 0; it < EP_IT; ++it) {
+            const int r = (elane >> 3) + 8 * it;
+            const int m = m0 + wr * WTM_FULL + part * WTM + r;
+            valid[it] = m < p.M;
+            const int mc = valid[it] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
+            int orow = mc, rr = mc;
+            if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
+                if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
+                if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
+            }
+            c_off[it] = (uint32_t)orow * (uint32_t)p.ldc + wn0 + ec * 8;
+            r_off[it] = (uint32_t)rr * (uint32_t)p.ldres + wn0 + ec * 8;
         }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
-#pragma unroll
-    for (int it = 0; it < EP_IT; ++it) {
-        const int r = (elane >> 3) + 8 * it;
-        u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
+        // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
+        // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
         if (p.res) {
-            // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
+            for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
         }
-        if (valid[it]) *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+        // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
+        if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                const f32x4 v = acc[i][part * MI + j];
+                const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
+                const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
+                u32x2 o;
+                o[0] = pack2bf(lo[0], lo[1]);
+                o[1] = pack2bf(hi[0], hi[1]);
+                const int row = j * 16 + frow;
+                const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
+                *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int r = (elane >> 3) + 8 * it;
+            u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
+            if (p.res) {
+                // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
+            }
+            if (valid[it]) *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+        }
     }
 }
 
@@ -323,6 +330,209 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     gemm_epilogue<WTM, WTN, REMAP, ACT>(p, acc, smem, wave, lane, m0, n0, wr, wc);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 256 x 256 tile, eight phases per two K-tiles (cdna_hip_programming.md section 5, "The 256^2 8-phase template").
+// 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave, two 64 KB LDS buffers. A K-tile is four phases; each phase
+// loads one register sub-tile from LDS, issues one quarter of a later K-tile's LDS-DMA (2 pieces per wave), and
+// runs the 16 MFMAs of one 64 x 32 output quadrant between two barriers:
+//
+//   phase 1: read A rows [0,64) + B cols [0,32) of the wave tile   DMA B-late(t+1)   MFMA quadrant (0,0)
+//   phase 2: read B cols [32,64)                                    DMA A-late(t+1)   MFMA quadrant (0,1)
+//   phase 3: read A rows [64,128)                                   DMA A-early(t+2)  MFMA quadrant (1,1)
+//   phase 4: -                             DMA B-early(t+2), wait tile t+1 landed     MFMA quadrant (1,0)
+//
+// "early" / "late" quarters of a tile are the row sets read in phase 1 / in phases 2-3 (for every wave at once:
+// A-early = tile rows {0-63, 128-191}, B-early = tile columns {64c .. 64c+31}), so a quarter of the CURRENT buffer is
+// free to be overwritten by tile t+2 two phases after its only read, and each wave has at most 8 DMAs outstanding.
+// Waves 4-7 run one barrier behind waves 0-3 (an extra s_barrier up front, balanced at the end): on every SIMD one
+// wave is in its MFMA section (raised priority) while its partner is in its load section.
+// Ordering: the only vmcnt wait is in phase 4 (leaves the 4 youngest DMAs = two quarters of tile t+2 in flight) and
+// sits before that phase's first barrier; tile t+1 is first read one phase later, after two more barriers, by which
+// time the trailing wave group has executed the same wait (rule "read a staged buffer one phase AFTER the wait that
+// retires it", one barrier more because of the stagger).
+// ---------------------------------------------------------------------------------------------------------
+template <bool REMAP, int ACT>
+__global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, MI = 8, NI = 4;
+    constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = (BM + BN) * ROW_BYTES;  // 32 KB, 64 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int tilesM = (p.M + BM - 1) / BM, tilesN = p.N / BN;
+    const int nwg = tilesM * tilesN;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int GM = p.group_m > 0 ? p.group_m : 4;
+    const int per_group = GM * tilesN;
+    const int grp = id / per_group;
+    const int first_m = grp * GM;
+    const int gsz = (tilesM - first_m) < GM ? (tilesM - first_m) : GM;
+    const int in_grp = id - grp * per_group;
+    const int m0 = (first_m + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
+
+    // per-lane DMA sources at kt = 0; [s] = early / late quarter, [u] = this wave's two 8-row pieces of the quarter
+    const bf16_t* a_src[2][2];
+    const bf16_t* b_src[2][2];
+    const int r8 = lane >> 3, sw8 = ((lane & 7) ^ r8) * 8;
+#pragma unroll
+    for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
+            grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
+            a_src[sq][u] = p.A + (size_t)grow * p.lda + sw8;
+            const int nrow = n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (wave & 3) * 8 + r8;
+            b_src[sq][u] = p.W + (size_t)nrow * p.ldw + sw8;
+        }
+    auto dma = [&](const bf16_t* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+    };
+    auto dma_a = [&](int sq, int t, int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * BK, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+    };
+    auto dma_b = [&](int sq, int t, int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            dma(b_src[sq][u] + t * BK, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.K / BK;
+    const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
+    const int a_rd = (wr * WTM + frow) * ROW_BYTES, b_rd = A_BYTES + (wc * WTN + frow) * ROW_BYTES;
+    const int coff0 = ((0 + fq) ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
+
+    // prologue: all of tile 0 and the early quarters of tile 1
+    dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
+    if (nkt > 1) { dma_a(0, 1, 1); dma_b(0, 1, 1); }
+    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");  // trailing group: one barrier behind from here on
+
+    bf16x8 af[4][2];      // current 64-row half of the wave's A rows, both K halves
+    bf16x8 wf[2][2][2];   // both 32-column halves of the wave's W rows
+    auto read_a = [&](int buf, int mh) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const char* base = smem + buf * BUF_BYTES + a_rd + (mh * 4 + jj) * 16 * ROW_BYTES;
+            af[jj][0] = *(const bf16x8*)(base + coff0);
+            af[jj][1] = *(const bf16x8*)(base + coff1);
+        }
+    };
+    auto read_w = [&](int buf, int nh) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const char* base = smem + buf * BUF_BYTES + b_rd + (nh * 2 + ii) * 16 * ROW_BYTES;
+            wf[nh][ii][0] = *(const bf16x8*)(base + coff0);
+            wf[nh][ii][1] = *(const bf16x8*)(base + coff1);
+        }
+    };
+    auto quadrant = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    acc[nh * 2 + ii][mh * 4 + jj] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][ii][kk], af[jj][kk], acc[nh * 2 + ii][mh * 4 + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#define MERV_PH_LOADED()                                                   \
+    do {                                                                    \
+        asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#define MERV_PH_DONE()                                  \
+    do {                                                 \
+        __builtin_amdgcn_sched_barrier(0);               \
+        asm volatile("s_barrier" ::: "memory");          \
+        __builtin_amdgcn_sched_barrier(0);               \
+    } while (0)
+    // one K-tile; MODE 0: tiles t+1 and t+2 exist, 1: only t+1 (second-last tile), 2: last tile -- compile-time, so every
+    // body is straight-line code (the launcher only takes this kernel for an even number of K-tiles >= 4)
+    auto k_tile = [&](int t, auto buf_tag, auto mode_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
+        // phase 1
+        read_w(BUF, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(BUF, 0);
+        if constexpr (has1) dma_b(1, t + 1, BUF ^ 1);
+        MERV_PH_LOADED();
+        quadrant(0, 0);
+        MERV_PH_DONE();
+        // phase 2
+        read_w(BUF, 1);
+        if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
+        MERV_PH_LOADED();
+        quadrant(0, 1);
+        MERV_PH_DONE();
+        // phase 3
+        read_a(BUF, 1);
+        if constexpr (has2) dma_a(0, t + 2, BUF);
+        MERV_PH_LOADED();
+        quadrant(1, 1);
+        MERV_PH_DONE();
+        // phase 4
+        if constexpr (has2) {
+            dma_b(0, t + 2, BUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else if constexpr (has1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        MERV_PH_LOADED();
+        quadrant(1, 0);
+        MERV_PH_DONE();
+    };
+    int t = 0;
+    for (; t + 2 < nkt; t += 2) {
+        k_tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        k_tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    }
+    k_tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    k_tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+#undef MERV_PH_LOADED
+#undef MERV_PH_DONE
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance the trailing group's extra barrier
+
+    gemm_epilogue<WTM, WTN, REMAP, ACT, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+}
+
+template <bool REMAP, int ACT>
+hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES;  // 128 KB
+    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tilesM = (a.M + 255) / 256, tilesN = a.N / 256;
+    hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), LDS, s, a);
+    return hipGetLastError();
+}
+template <int ACT>
+hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
+    if (a.out_group > 0 || a.res_row_mod > 0) {
+        if constexpr (ACT == ACT_NONE) return launch_8phase2<true, ACT>(a, s);
+        else return hipErrorInvalidValue;
+    }
+    return launch_8phase2<false, ACT>(a, s);
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT>
 hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = NSTAGE * (BM + BN) * ROW_BYTES;
@@ -352,14 +562,39 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 int g_gemm_variant = 0;
 int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
-// Tile choice (measured on MI355X, tools/gemm_bench.py, profiles/r01_gemm_tiles.md): the 256x128 tile with a 3-deep
-// LDS ring and staggered half-blocks is the fastest configuration whenever it yields enough blocks to occupy the
-// chip; small launches use 128x128 tiles, two blocks per CU. The 256x256 tile has the best bytes/FLOP but pays the
-// longest per-tile prologue + epilogue and the worst last-round quantisation (one block per CU).
+// Tile choice (measured on MI355X, tools/gemm_bench.py): the 256x256 eight-phase kernel has by far the best in-round
+// rate (~1.2 PFLOP/s at K = 1024, ~1.5 at K = 4096) but one block per CU and 256-row granularity, so a launch whose
+// tile count is not a multiple of the CU count loses up to a whole round. plan_split() therefore gives it only the
+// leading m-tiles that fill complete rounds of the chip; the remaining rows (incl. the ragged last m-tile) go to the
+// 256x128 staggered kernel, or to 128x128 tiles (two blocks per CU) when that is too few blocks to occupy the chip.
 int choose_variant(const GemmArgs& a) {
     if (g_gemm_variant) return g_gemm_variant;
     const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);
     return tiles >= 160 ? 4 : 1;
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// rows (a multiple of 256, possibly 0) the eight-phase kernel should take from the top of the problem
+int plan_split(const GemmArgs& a) {
+    if (g_gemm_variant != 0) return 0;
+    const int nkt = a.K / BK;
+    if (a.N % 256 != 0 || nkt < 4 || (nkt & 1) || a.out_group > 0 || a.res_row_mod > 0) return 0;
+    const long tilesN = a.N / 256, full_m = a.M / 256;
+    const long rounds = full_m * tilesN / num_cus();
+    if (rounds < 1) return 0;
+    long k = rounds * num_cus() / tilesN;
+    if (k > full_m) k = full_m;
+    return (int)(k * 256);
 }
 
 template <int ACT>
@@ -369,6 +604,9 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
         case 3: return launch_cfg<256, 128, 4, 2, 3, false, ACT>(a, s);
         case 4: return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
         case 5: return launch_cfg<256, 256, 2, 4, 2, true, ACT>(a, s);
+        case 7:
+            if (a.N % 256 == 0 && (a.K / BK) % 2 == 0 && a.K / BK >= 4) return launch_8phase<ACT>(a, s);
+            return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
         default: return launch_cfg<128, 128, 2, 2, 2, false, ACT>(a, s);
     }
 }
@@ -392,13 +630,27 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (g_gemm_variant == 2 && a.N % 256 != 0) return hipErrorInvalidValue;
     ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
                  2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2 : 1)));
-    switch (a.act) {
-        case ACT_NONE: return launch_act<ACT_NONE>(a, s);
-        case ACT_GELU_ERF: return launch_act<ACT_GELU_ERF>(a, s);
-        case ACT_GELU_TANH: return launch_act<ACT_GELU_TANH>(a, s);
-        case ACT_QUICK_GELU: return launch_act<ACT_QUICK_GELU>(a, s);
-        default: return hipErrorInvalidValue;
-    }
+    auto dispatch = [&](const GemmArgs& g, bool eight_phase) -> hipError_t {
+        switch (g.act) {
+            case ACT_NONE: return eight_phase ? launch_8phase<ACT_NONE>(g, s) : launch_act<ACT_NONE>(g, s);
+            case ACT_GELU_ERF: return eight_phase ? launch_8phase<ACT_GELU_ERF>(g, s) : launch_act<ACT_GELU_ERF>(g, s);
+            case ACT_GELU_TANH: return eight_phase ? launch_8phase<ACT_GELU_TANH>(g, s) : launch_act<ACT_GELU_TANH>(g, s);
+            case ACT_QUICK_GELU: return eight_phase ? launch_8phase<ACT_QUICK_GELU>(g, s) : launch_act<ACT_QUICK_GELU>(g, s);
+            default: return hipErrorInvalidValue;
+        }
+    };
+    const int rows1 = plan_split(a);
+    if (rows1 == 0) return dispatch(a, false);
+    GemmArgs top = a;
+    top.M = rows1;
+    hipError_t e = dispatch(top, true);
+    if (e != hipSuccess || rows1 == a.M) return e;
+    GemmArgs rest = a;  // independent rows: same stream, no ordering requirement between the two launches
+    rest.M = a.M - rows1;
+    rest.A = a.A + (size_t)rows1 * a.lda;
+    rest.C = a.C + (size_t)rows1 * a.ldc;
+    if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
+    return dispatch(rest, false);
 }
 
 }  // namespace merv
