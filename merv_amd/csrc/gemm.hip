@@ -562,17 +562,6 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 int g_gemm_variant = 0;
 int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
-// Tile choice (measured on MI355X, tools/gemm_bench.py): the 256x256 eight-phase kernel has by far the best in-round
-// rate (~1.2 PFLOP/s at K = 1024, ~1.5 at K = 4096) but one block per CU and 256-row granularity, so a launch whose
-// tile count is not a multiple of the CU count loses up to a whole round. plan_split() therefore gives it only the
-// leading m-tiles that fill complete rounds of the chip; the remaining rows (incl. the ragged last m-tile) go to the
-// 256x128 staggered kernel, or to 128x128 tiles (two blocks per CU) when that is too few blocks to occupy the chip.
-int choose_variant(const GemmArgs& a) {
-    if (g_gemm_variant) return g_gemm_variant;
-    const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);
-    return tiles >= 160 ? 4 : 1;
-}
-
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -582,6 +571,21 @@ int num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+// Tile choice (measured on MI355X, tools/gemm_bench.py): the 256x256 eight-phase kernel has by far the best in-round
+// rate (~1.2 PFLOP/s at K = 1024, ~1.5 at K = 4096) but one block per CU and 256-row granularity, so a launch whose
+// tile count is not a multiple of the CU count loses up to a whole round. plan_split() therefore gives it only the
+// leading m-tiles that fill complete rounds of the chip; the remaining rows (incl. the ragged last m-tile) go to the
+// 256x128 staggered kernel, or to 128x128 tiles (two blocks per CU) when that is too few blocks to occupy the chip.
+int choose_variant(const GemmArgs& a) {
+    if (g_gemm_variant) return g_gemm_variant;
+    const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);
+    if (tiles >= 160) return 4;
+    // few blocks: at most one 128x128 block per CU, so co-residency cannot hide the DMA latency of a 2-deep ring
+    // (a lone block then runs ~1.3 us per K-step); a 4-deep ring keeps three tiles in flight instead
+    const long small_tiles = (long)((a.M + 127) / 128) * (a.N / 128);
+    return small_tiles <= num_cus() ? 6 : 1;
 }
 
 // rows (a multiple of 256, possibly 0) the eight-phase kernel should take from the top of the problem
@@ -604,6 +608,7 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
         case 3: return launch_cfg<256, 128, 4, 2, 3, false, ACT>(a, s);
         case 4: return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
         case 5: return launch_cfg<256, 256, 2, 4, 2, true, ACT>(a, s);
+        case 6: return launch_cfg<128, 128, 2, 2, 4, false, ACT>(a, s);
         case 7:
             if (a.N % 256 == 0 && (a.K / BK) % 2 == 0 && a.K / BK >= 4) return launch_8phase<ACT>(a, s);
             return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);

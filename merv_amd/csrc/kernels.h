@@ -21,7 +21,8 @@ struct GemmArgs {
     int group_m;      // 0 = default; m-tiles per column sweep of the tile order (L2 locality knob)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
-void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128, 4/5: staggered 256x128 / 256x256;
+void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128, 4/5: staggered 256x128 / 256x256, 6: 128x128 4-deep ring,
+                               // 7: 256x256 eight-phase;
                                // second byte: tile-order group size override (tuning / tests)
 
 // Row LayerNorm (fp32 statistics), optional fused "x += add[(row / add_div) % add_mod]" written back in place
