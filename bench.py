@@ -229,7 +229,8 @@ def main():
             tf = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
             if tf.exists():
                 try:
-                    traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+                    per_step = json.loads(tf.read_text()).get("hbm_bytes_per_step")
+                    traffic = per_step / (n.value / args.steps) if per_step else None  # per GEMM call, like `achieved`
                 except Exception:
                     traffic = None
             roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all tile configs, all launches of the step)",

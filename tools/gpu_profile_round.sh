@@ -35,9 +35,14 @@ for k in fe:
     f_kb, nf = fe[k]; w_kb, nw = wr.get(k, (0.0, 1))
     res[k] = {"launches": nf, "fetch_size_kb_per_launch_raw": f_kb / nf, "write_size_kb_per_launch": w_kb / max(nw, 1),
               "hbm_bytes_per_launch": (2.0 * f_kb / nf + w_kb / max(nw, 1)) * 1024.0}
-doc = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --sequential --steps 2 --warmup 1`; "
-               "gfx950: FETCH_SIZE counts 128-B requests at 64 B, so reads are doubled (MI355X_MICROARCH.md, HBM)",
-       "hbm_bytes_per_launch": res.get("gemm", {}).get("hbm_bytes_per_launch"), "kernels": res}
+STEPS = 3  # 1 warm-up + 2 timed steps, no roofline leg (--no-prof)
+g = res.get("gemm", {})
+doc = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --sequential --steps 2 --warmup 1 "
+               "--no-prof` (3 steps); gfx950: FETCH_SIZE counts 128-B requests at 64 B, so reads are doubled (MI355X_MICROARCH.md, "
+               "HBM). One GEMM call of the library may be two kernel launches (eight-phase part + remaining rows): "
+               "hbm_bytes_per_step sums all GEMM kernels of a step; bench.py divides it by the GEMM calls per step.",
+       "steps_in_run": STEPS, "hbm_bytes_per_launch": g.get("hbm_bytes_per_launch"),
+       "hbm_bytes_per_step": (g.get("hbm_bytes_per_launch", 0.0) * g.get("launches", 0) / STEPS) if g else None, "kernels": res}
 json.dump(doc, open(f"{out}/pmc_gemm_traffic.json", "w"), indent=1)
 print(json.dumps(doc)[:600])
 PY
