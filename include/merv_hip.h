@@ -171,6 +171,23 @@ int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M,
                             void *ws, size_t ws_bytes, void *grad_w, float *grad_b, void *stream);
 
 /* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
+/*
+ * ---- MXFP8 mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs") ----
+ * OCP Microscaling FP8: e4m3 elements, one E8M0 scale per 32 consecutive k (shared exponent floor(log2 amax) - 8,
+ * round-to-nearest-even, saturation at +-448), consumed by v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA
+ * rate. There is no counterpart in the reference (it runs bf16 autocast, merv.py:816): this mode trades the bf16
+ * tolerance for throughput and is never the default.
+ * merv_quantize_mxfp8: x bf16 [rows, K] (ld elements) -> q [rows, K] bytes + scales (merv_mxfp8_scale_bytes(rows, K)
+ *   bytes, in the GEMM's lane order: [K/128][ceil(rows/64)][(kblock%4)*16 + row%16][(row%64)/16]). K % 128 == 0.
+ * merv_gemm_mxfp8: C[M,N] bf16 = epilogue(A8 . W8^T), same epilogue arguments as merv_gemm_bf16 (bias, activation,
+ *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
+ */
+size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K);
+int merv_quantize_mxfp8(const void *x, int32_t rows, int32_t K, int32_t ld, void *q, void *scales, void *stream);
+int merv_gemm_mxfp8(const void *A8, const void *scale_a, const void *W8, const void *scale_w, void *C, const float *bias,
+                    const float *lscale, const void *res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                    int32_t ldc, int32_t ldres, int32_t act, void *stream);
+
 /* out[c][r] = in[r][c] (bf16), columns R..Rpad-1 of `out` zero-filled; ldi, ldo, Rpad even. */
 int merv_transpose_bf16(const void *in, int32_t R, int32_t C, int32_t ldi, void *out, int32_t ldo, int32_t Rpad,
                         void *stream);

@@ -365,6 +365,36 @@ extern "C" int merv_transpose_bf16(const void* in, int32_t R, int32_t C, int32_t
     return 0;
 }
 
+// ---- MXFP8 mode ----
+extern "C" size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K) {
+    if (rows <= 0 || K <= 0 || K % 128 != 0) return 0;
+    return mx_scale_bytes(rows, K);
+}
+
+extern "C" int merv_quantize_mxfp8(const void* x, int32_t rows, int32_t K, int32_t ld, void* q, void* scales, void* stream_) {
+    MERV_CHECK(x && q && scales, "merv_quantize_mxfp8: null argument");
+    MERV_CHECK(rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld >= K, "merv_quantize_mxfp8: need K % 128 == 0, ld % 8 == 0, ld >= K");
+    MxQuantArgs a{(const bf16_t*)x, (uint8_t*)q, (uint8_t*)scales, rows, K, ld};
+    MERV_HIP(launch_mx_quantize(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_gemm_mxfp8(const void* A8, const void* scale_a, const void* W8, const void* scale_w, void* C, const float* bias,
+                               const float* lscale, const void* res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
+                               int32_t ldc, int32_t ldres, int32_t act, void* stream_) {
+    MERV_CHECK(A8 && scale_a && W8 && scale_w && C, "merv_gemm_mxfp8: null argument");
+    MERV_CHECK(M > 0 && N > 0 && N % 256 == 0 && K >= 512 && K % 256 == 0, "merv_gemm_mxfp8: need N % 256 == 0, K % 256 == 0, K >= 512");
+    MERV_CHECK(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldc % 8 == 0 && ldc >= N, "merv_gemm_mxfp8: bad leading dimension");
+    MERV_CHECK(act >= ACT_NONE && act <= ACT_QUICK_GELU, "merv_gemm_mxfp8: unknown activation");
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = (const bf16_t*)A8; g.W = (const bf16_t*)W8; g.C = (bf16_t*)C; g.bias = bias; g.lscale = lscale; g.res = (const bf16_t*)res;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldres = ldres; g.act = act;
+    g.mx_scale_a = scale_a; g.mx_scale_w = scale_w; g.mx_groups_a = (M + 63) / 64; g.mx_groups_w = N / 64;
+    MERV_HIP(launch_gemm_mx(g, (hipStream_t)stream_));
+    return 0;
+}
+
 // ---- frame preprocessing (row a3) ----
 extern "C" size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t out_size) {
     if (T <= 0 || H <= 0 || W <= 0 || out_size <= 0) return 0;

@@ -351,10 +351,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
 // time the trailing wave group has executed the same wait (rule "read a staged buffer one phase AFTER the wait that
 // retires it", one barrier more because of the stagger).
 // ---------------------------------------------------------------------------------------------------------
-template <bool REMAP, int ACT>
+template <bool REMAP, int ACT, bool MX>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
+    // MX = true: the same schedule on MXFP8 operands (OCP e4m3 elements, one E8M0 scale per 32 elements of K,
+    // v_mfma_scale_f32_16x16x128_f8f6f4: twice the bf16 MFMA rate and half the operand bytes). A K-tile is still 128
+    // bytes per row (128 fp8 elements instead of 64 bf16), so the LDS image, the DMA pieces and the two ds_read_b128
+    // per fragment are byte-identical: the instruction's operand is [16 bytes of k = 16g..] ++ [16 bytes of k = 64+16g..]
+    // for lane group g (probed with exact integer data, tools/probes/mx_layout_probe.hip), i.e. chunks g and 4+g of the
+    // row. What is added: one 256-byte scale DMA per wave per K-tile and three ds_read_b32 per wave per K-tile.
     constexpr int BM = 256, BN = 256, WTM = 128, WTN = 64, MI = 8, NI = 4;
     constexpr int A_BYTES = BM * ROW_BYTES, BUF_BYTES = (BM + BN) * ROW_BYTES;  // 32 KB, 64 KB
+    constexpr int ES = MX ? 1 : 2;                // bytes per operand element
+    constexpr int BKE = ROW_BYTES / ES;           // elements of K per K-tile
+    constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -372,31 +381,48 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     const int m0 = (first_m + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
 
     // per-lane DMA sources at kt = 0; [s] = early / late quarter, [u] = this wave's two 8-row pieces of the quarter
-    const bf16_t* a_src[2][2];
-    const bf16_t* b_src[2][2];
-    const int r8 = lane >> 3, sw8 = ((lane & 7) ^ r8) * 8;
+    const char* a_src[2][2];
+    const char* b_src[2][2];
+    const int r8 = lane >> 3, sw8 = ((lane & 7) ^ r8) * 16;  // source-side swizzle, in bytes
 #pragma unroll
     for (int sq = 0; sq < 2; ++sq)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
             grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
-            a_src[sq][u] = p.A + (size_t)grow * p.lda + sw8;
+            a_src[sq][u] = (const char*)p.A + (size_t)grow * p.lda * ES + sw8;
             const int nrow = n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (wave & 3) * 8 + r8;
-            b_src[sq][u] = p.W + (size_t)nrow * p.ldw + sw8;
+            b_src[sq][u] = (const char*)p.W + (size_t)nrow * p.ldw * ES + sw8;
         }
-    auto dma = [&](const bf16_t* src, int lds_off) {
+    auto dma = [&](const char* src, int lds_off) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
     auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * BK, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            dma(b_src[sq][u] + t * BK, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
+            dma(b_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
+    };
+    // MX block scales, layout [K-tile][64-row group][lane = 16 * kblock + row % 16][(row % 64) / 16] bytes: waves 0-3
+    // bring the A groups of this tile's 256 rows, waves 4-7 the W groups (256 B each, 4 B per lane)
+    const char* s_base = nullptr;  // wave-uniform: this wave's 64-row group of K-tile 0
+    size_t s_stride = 0;           // bytes between K-tiles
+    if constexpr (MX) {
+        const bool is_w = wave >= 4;
+        const int gtot = is_w ? p.mx_groups_w : p.mx_groups_a;
+        int gidx = (is_w ? n0 : m0) / 64 + (wave & 3);
+        gidx = gidx < gtot ? gidx : gtot - 1;
+        s_base = (const char*)(is_w ? p.mx_scale_w : p.mx_scale_a) + (size_t)gidx * 256;
+        s_stride = (size_t)gtot * 256;
+    }
+    auto dma_s = [&](int t, int buf) {
+        if constexpr (MX)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_base + t * s_stride + (size_t)(uint32_t)(lane * 4)),
+                                             (__attribute__((address_space(3))) void*)(smem + SC_BASE + buf * 2048 + wave * 256), 4, 0, 0);
     };
 
     f32x4 acc[NI][MI];
@@ -405,49 +431,121 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = p.K / BK;
+    const int nkt = p.K / BKE;
     const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
     const int a_rd = (wr * WTM + frow) * ROW_BYTES, b_rd = A_BYTES + (wc * WTN + frow) * ROW_BYTES;
     const int coff0 = ((0 + fq) ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
 
-    // prologue: all of tile 0 and the early quarters of tile 1
+    // prologue: all of tile 0 and the early quarters of tile 1 (the launcher guarantees nkt >= 4)
+    dma_s(0, 0);
     dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
-    if (nkt > 1) { dma_a(0, 1, 1); dma_b(0, 1, 1); }
-    if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_a(0, 1, 1); dma_b(0, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // trailing group: one barrier behind from here on
 
-    bf16x8 af[4][2];      // current 64-row half of the wave's A rows, both K halves
-    bf16x8 wf[2][2][2];   // both 32-column halves of the wave's W rows
+    typedef int v8i_t __attribute__((ext_vector_type(8)));
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    bf16x8 af[4][2];      // bf16: current 64-row half of the wave's A rows, both K halves
+    bf16x8 wf[2][2][2];   // bf16: both 32-column halves of the wave's W rows
+    v8i_t af8[4];         // MX: the same fragments as 32-byte operands (chunks g and 4+g of the row)
+    v8i_t wf8[2][2];
+    int sc_a[2] = {0, 0}, sc_w = 0;  // MX: scale dwords (one byte per row fragment) of the current K-tile
+    auto load32 = [&](const char* base) {
+        const v4i_t l = *(const v4i_t*)(base + coff0), h = *(const v4i_t*)(base + coff1);
+        return v8i_t{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+    };
     auto read_a = [&](int buf, int mh) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const char* base = smem + buf * BUF_BYTES + a_rd + (mh * 4 + jj) * 16 * ROW_BYTES;
-            af[jj][0] = *(const bf16x8*)(base + coff0);
-            af[jj][1] = *(const bf16x8*)(base + coff1);
+            if constexpr (MX) {
+                af8[jj] = load32(base);
+            } else {
+                af[jj][0] = *(const bf16x8*)(base + coff0);
+                af[jj][1] = *(const bf16x8*)(base + coff1);
+            }
         }
     };
     auto read_w = [&](int buf, int nh) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
             const char* base = smem + buf * BUF_BYTES + b_rd + (nh * 2 + ii) * 16 * ROW_BYTES;
-            wf[nh][ii][0] = *(const bf16x8*)(base + coff0);
-            wf[nh][ii][1] = *(const bf16x8*)(base + coff1);
+            if constexpr (MX) {
+                wf8[nh][ii] = load32(base);
+            } else {
+                wf[nh][ii][0] = *(const bf16x8*)(base + coff0);
+                wf[nh][ii][1] = *(const bf16x8*)(base + coff1);
+            }
         }
     };
-    auto quadrant = [&](int mh, int nh) {
+    auto read_scales = [&](int buf) {
+        if constexpr (MX) {
+            const char* sb = smem + SC_BASE + buf * 2048 + lane * 4;
+            sc_a[0] = *(const int*)(sb + (2 * wr) * 256);
+            sc_a[1] = *(const int*)(sb + (2 * wr + 1) * 256);
+            sc_w = *(const int*)(sb + 1024 + wc * 256);
+        }
+    };
+    // The scaled MFMA goes through inline asm with the accumulator as a tied "+v" operand: the compiler's own selection of
+    // this instruction never accumulates in place (destination != source C: it doubled the accumulator registers and
+    // copied them every iteration). The scale byte is an instruction field: byte b of the dword = op_sel bit (b & 1),
+    // op_sel_hi bit (b >> 1), first slot for the first operand. Hazards the compiler cannot see inside asm are avoided
+    // by construction: operands come straight from ds_read (waited for by lgkmcnt(0)), each accumulator is touched once
+    // per K-tile, and the epilogue is separated from the last MFMA by barriers plus explicit s_nops.
+#define MERV_MX_ASM(ACC, WOP, AOP, SW, SA, OL0, OL1, OH0, OH1)                                                          \
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[" #OL0 "," #OL1 ",0] op_sel_hi:[" #OH0 \
+                 "," #OH1 ",0]"                                                                                          \
+                 : "+v"(ACC)                                                                                             \
+                 : "v"(WOP), "v"(AOP), "v"(SW), "v"(SA))
+    auto mx_mma = [&](f32x4& c, const v8i_t& w8, const v8i_t& a8, int sw_, int sa_, auto wb_tag, auto ab_tag) {
+        constexpr int wb = decltype(wb_tag)::value, ab = decltype(ab_tag)::value;
+        if constexpr (wb == 0 && ab == 0) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 0, 0, 0);
+        if constexpr (wb == 0 && ab == 1) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 1, 0, 0);
+        if constexpr (wb == 0 && ab == 2) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 0, 0, 1);
+        if constexpr (wb == 0 && ab == 3) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 1, 0, 1);
+        if constexpr (wb == 1 && ab == 0) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 0, 0, 0);
+        if constexpr (wb == 1 && ab == 1) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 1, 0, 0);
+        if constexpr (wb == 1 && ab == 2) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 0, 0, 1);
+        if constexpr (wb == 1 && ab == 3) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 1, 0, 1);
+        if constexpr (wb == 2 && ab == 0) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 0, 1, 0);
+        if constexpr (wb == 2 && ab == 1) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 1, 1, 0);
+        if constexpr (wb == 2 && ab == 2) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 0, 1, 1);
+        if constexpr (wb == 2 && ab == 3) MERV_MX_ASM(c, w8, a8, sw_, sa_, 0, 1, 1, 1);
+        if constexpr (wb == 3 && ab == 0) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 0, 1, 0);
+        if constexpr (wb == 3 && ab == 1) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 1, 1, 0);
+        if constexpr (wb == 3 && ab == 2) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 0, 1, 1);
+        if constexpr (wb == 3 && ab == 3) MERV_MX_ASM(c, w8, a8, sw_, sa_, 1, 1, 1, 1);
+    };
+#define MERV_MX_MMA(I, J, WI, AJ, SA) \
+    mx_mma(acc[I][J], wf8[(WI) >> 1][(WI) & 1], af8[AJ], sc_w, SA, std::integral_constant<int, (WI)>{}, std::integral_constant<int, (AJ)>{})
+    auto quadrant = [&](auto mh_tag, auto nh_tag) {
+        constexpr int mh = decltype(mh_tag)::value, nh = decltype(nh_tag)::value;
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (MX) {
+            const int sa = sc_a[mh];
+            MERV_MX_MMA(nh * 2 + 0, mh * 4 + 0, nh * 2 + 0, 0, sa);
+            MERV_MX_MMA(nh * 2 + 0, mh * 4 + 1, nh * 2 + 0, 1, sa);
+            MERV_MX_MMA(nh * 2 + 0, mh * 4 + 2, nh * 2 + 0, 2, sa);
+            MERV_MX_MMA(nh * 2 + 0, mh * 4 + 3, nh * 2 + 0, 3, sa);
+            MERV_MX_MMA(nh * 2 + 1, mh * 4 + 0, nh * 2 + 1, 0, sa);
+            MERV_MX_MMA(nh * 2 + 1, mh * 4 + 1, nh * 2 + 1, 1, sa);
+            MERV_MX_MMA(nh * 2 + 1, mh * 4 + 2, nh * 2 + 1, 2, sa);
+            MERV_MX_MMA(nh * 2 + 1, mh * 4 + 3, nh * 2 + 1, 3, sa);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+                for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)
-                    acc[nh * 2 + ii][mh * 4 + jj] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][ii][kk], af[jj][kk], acc[nh * 2 + ii][mh * 4 + jj], 0, 0, 0);
+                    for (int jj = 0; jj < 4; ++jj)
+                        acc[nh * 2 + ii][mh * 4 + jj] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][ii][kk], af[jj][kk], acc[nh * 2 + ii][mh * 4 + jj], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 #define MERV_PH_LOADED()                                                   \
     do {                                                                    \
         asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    \
@@ -466,24 +564,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
         // phase 1
+        read_scales(BUF);
         read_w(BUF, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(BUF, 0);
-        if constexpr (has1) dma_b(1, t + 1, BUF ^ 1);
+        if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
         MERV_PH_LOADED();
-        quadrant(0, 0);
+        quadrant(I0{}, I0{});
         MERV_PH_DONE();
         // phase 2
         read_w(BUF, 1);
         if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
         MERV_PH_LOADED();
-        quadrant(0, 1);
+        quadrant(I0{}, I1{});
         MERV_PH_DONE();
         // phase 3
         read_a(BUF, 1);
         if constexpr (has2) dma_a(0, t + 2, BUF);
         MERV_PH_LOADED();
-        quadrant(1, 1);
+        quadrant(I1{}, I1{});
         MERV_PH_DONE();
         // phase 4
         if constexpr (has2) {
@@ -493,27 +592,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         MERV_PH_LOADED();
-        quadrant(1, 0);
+        quadrant(I1{}, I0{});
         MERV_PH_DONE();
     };
     int t = 0;
     for (; t + 2 < nkt; t += 2) {
-        k_tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        k_tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        k_tile(t, I0{}, I0{});
+        k_tile(t + 1, I1{}, I0{});
     }
-    k_tile(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    k_tile(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    k_tile(t, I0{}, I1{});
+    k_tile(t + 1, I1{}, std::integral_constant<int, 2>{});
 #undef MERV_PH_LOADED
 #undef MERV_PH_DONE
+#undef MERV_MX_MMA
+#undef MERV_MX_ASM
+    if constexpr (MX) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // MFMA results vs. the epilogue's reads
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance the trailing group's extra barrier
 
     gemm_epilogue<WTM, WTN, REMAP, ACT, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
 }
 
-template <bool REMAP, int ACT>
+template <bool REMAP, int ACT, bool MX = false>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES;  // 128 KB
-    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT>;
+    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
+    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -532,6 +634,8 @@ hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
     }
     return launch_8phase2<false, ACT>(a, s);
 }
+template <int ACT>
+hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) { return launch_8phase2<false, ACT, true>(a, s); }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT>
 hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
@@ -656,6 +760,25 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     rest.C = a.C + (size_t)rows1 * a.ldc;
     if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
     return dispatch(rest, false);
+}
+
+// MXFP8 GEMM (A, W: OCP e4m3 bytes, row-major, K contiguous; block scales in the layout mx_quantize writes).
+// Requirements: K % 256 == 0 and K >= 512 (an even number >= 4 of 128-element K-tiles), N % 256 == 0, no row remapping.
+hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (!a.mx_scale_a || !a.mx_scale_w || a.mx_groups_a < (a.M + 63) / 64 || a.mx_groups_w < a.N / 64) return hipErrorInvalidValue;
+    if (a.K % 256 != 0 || a.K < 512 || a.N % 256 != 0 || a.out_group > 0 || a.res_row_mod > 0) return hipErrorInvalidValue;
+    if ((a.lda | a.ldw) % 16 != 0 || a.ldc % 8 != 0 || (a.res && a.ldres % 8 != 0)) return hipErrorInvalidValue;
+    if ((double)a.M * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
+    ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
+                 (double)a.M * a.K + (double)a.N * a.K + 2.0 * (double)a.M * a.N * (a.res ? 2 : 1));
+    switch (a.act) {
+        case ACT_NONE: return launch_8phase_mx<ACT_NONE>(a, s);
+        case ACT_GELU_ERF: return launch_8phase_mx<ACT_GELU_ERF>(a, s);
+        case ACT_GELU_TANH: return launch_8phase_mx<ACT_GELU_TANH>(a, s);
+        case ACT_QUICK_GELU: return launch_8phase_mx<ACT_QUICK_GELU>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace merv

@@ -19,8 +19,26 @@ struct GemmArgs {
     int out_off;
     int act;          // ACT_*
     int group_m;      // 0 = default; m-tiles per column sweep of the tile order (L2 locality knob)
+    // MXFP8 launches only (launch_gemm_mx): A / W then point to OCP e4m3 bytes (lda / ldw in elements = bytes)
+    const void* mx_scale_a;  // E8M0 block scales of A, layout of mx_quantize (below)
+    const void* mx_scale_w;
+    int mx_groups_a, mx_groups_w;  // 64-row groups in each scale array (ceil(rows / 64))
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s);
+
+// bf16 [rows, K] -> MXFP8: q [rows, K] OCP e4m3 bytes + one E8M0 scale per 32 consecutive k (OCP MX: shared exponent
+// floor(log2(amax)) - 8, elements rounded to nearest even and saturated to +-448). Scale layout, chosen so that the
+// GEMM's lane (row % 16, kblock % 4) reads the scales of four row fragments as one dword:
+//   scales[kblock / 4][row / 64][(kblock % 4) * 16 + row % 16][(row % 64) / 16]      (bytes; rows padded to 64)
+struct MxQuantArgs {
+    const bf16_t* x;  // [rows, K], leading dim ld
+    uint8_t* q;       // [rows, K] contiguous
+    uint8_t* scales;  // [K / 128][ceil(rows / 64)][64][4]
+    int rows, K, ld;
+};
+hipError_t launch_mx_quantize(const MxQuantArgs& a, hipStream_t s);
+size_t mx_scale_bytes(int rows, int K);
 void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128, 4/5: staggered 256x128 / 256x256, 6: 128x128 4-deep ring,
                                // 7: 256x256 eight-phase;
                                // second byte: tile-order group size override (tuning / tests)

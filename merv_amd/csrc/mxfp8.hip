@@ -1,0 +1,70 @@
+// MXFP8 quantisation for the fp8 encoder-GEMM mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs"). OCP
+// Microscaling: blocks of 32 consecutive k share one E8M0 scale 2^e, e = floor(log2(max|v|)) - 8 (8 = emax of e4m3);
+// elements are v / 2^e rounded to nearest even into OCP e4m3 and saturated to +-448. HBM-bound: reads 64 B, writes
+// 33 B per block; one lane per block, 16-byte accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace merv {
+namespace {
+
+__global__ __launch_bounds__(256) void mx_quantize_kernel(MxQuantArgs p) {
+    const int kblocks = p.K >> 5;
+    const long long total = (long long)p.rows * kblocks;
+    const int groups = (p.rows + 63) >> 6;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int row = (int)(i / kblocks), kb = (int)(i - (long long)row * kblocks);
+        const bf16_t* src = p.x + (size_t)row * p.ld + kb * 32;
+        u32x4 raw[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) raw[c] = *(const u32x4*)(src + c * 8);
+        float v[32];
+        float amax = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                v[c * 8 + 2 * w] = bflo(raw[c][w]);
+                v[c * 8 + 2 * w + 1] = bfhi(raw[c][w]);
+                amax = fmaxf(amax, fmaxf(fabsf(v[c * 8 + 2 * w]), fabsf(v[c * 8 + 2 * w + 1])));
+            }
+        // shared exponent: floor(log2(amax)) - 8, clamped to the E8M0 range; amax == 0 (or subnormal) -> smallest scale
+        int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+        e = e < -127 ? -127 : e;
+        const float inv = __uint_as_float((uint32_t)(127 - e) << 23);  // 2^-e, exponent field in [1, 254]
+        uint32_t outw[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            float a0 = v[4 * w] * inv, a1 = v[4 * w + 1] * inv, a2 = v[4 * w + 2] * inv, a3 = v[4 * w + 3] * inv;
+            a0 = fminf(fmaxf(a0, -448.f), 448.f);
+            a1 = fminf(fmaxf(a1, -448.f), 448.f);
+            a2 = fminf(fmaxf(a2, -448.f), 448.f);
+            a3 = fminf(fmaxf(a3, -448.f), 448.f);
+            int packed = 0;
+            packed = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, packed, false);
+            packed = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, packed, true);
+            outw[w] = (uint32_t)packed;
+        }
+        uint8_t* dst = p.q + (size_t)row * p.K + kb * 32;
+        *(u32x4*)dst = u32x4{outw[0], outw[1], outw[2], outw[3]};
+        *(u32x4*)(dst + 16) = u32x4{outw[4], outw[5], outw[6], outw[7]};
+        const size_t so = ((((size_t)(kb >> 2) * groups + (row >> 6)) * 64 + (kb & 3) * 16 + (row & 15)) << 2) + ((row & 63) >> 4);
+        p.scales[so] = (uint8_t)(e + 127);
+    }
+}
+
+}  // namespace
+
+size_t mx_scale_bytes(int rows, int K) { return (size_t)(K / 128) * ((rows + 63) / 64) * 256; }
+
+hipError_t launch_mx_quantize(const MxQuantArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.K <= 0 || a.K % 128 != 0 || a.ld % 8 != 0 || a.ld < a.K) return hipErrorInvalidValue;
+    const long long total = (long long)a.rows * (a.K / 32);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mx_quantize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace merv

@@ -105,3 +105,38 @@ def pool3d(tokens: torch.Tensor, T: int, S: int, out_size: int) -> torch.Tensor:
     rc = _lib.load().merv_pool3d(ptr(tokens), ptr(out), B, T, S, out_size, Cc, current_stream_ptr(tokens.device))
     check(rc, "merv_pool3d")
     return out
+
+
+# ---- MXFP8 mode (BASELINE.json configs[4]) ----
+def quantize_mxfp8(x: torch.Tensor):
+    """bf16 [rows, K] -> (q uint8 [rows, K] OCP e4m3, scales uint8 in the GEMM's lane order); include/merv_hip.h."""
+    lib = _lib.load()
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.stride(1) != 1 or not x.is_cuda:
+        raise ValueError("quantize_mxfp8: expected a CUDA bf16 [rows, K] tensor with contiguous rows")
+    rows, K = x.shape
+    if K % 128:
+        raise ValueError("quantize_mxfp8: K must be a multiple of 128")
+    q = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+    sc = torch.zeros(lib.merv_mxfp8_scale_bytes(rows, K), dtype=torch.uint8, device=x.device)
+    check(lib.merv_quantize_mxfp8(ptr(x), rows, K, x.stride(0), ptr(q), ptr(sc), current_stream_ptr(x.device)), "merv_quantize_mxfp8")
+    return q, sc
+
+
+def mxfp8_scales_to_rows(sc: torch.Tensor, rows: int, K: int) -> torch.Tensor:
+    """Un-permute the lane-order scale array to [rows, K/32] (tests / inspection)."""
+    groups = (rows + 63) // 64
+    s = sc.view(K // 128, groups, 4, 16, 4)  # [ktile][group][kblock%4][row%16][(row%64)/16]
+    s = s.permute(1, 4, 3, 0, 2).reshape(groups * 64, K // 32)  # row = 64*group + 16*j + r ; kblock = 4*ktile + kq
+    return s[:rows]
+
+
+def gemm_mxfp8(aq, a_sc, wq, w_sc, bias=None, act="none", lscale=None, res=None, out=None):
+    lib = _lib.load()
+    M, K = aq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=aq.device)
+    check(lib.merv_gemm_mxfp8(ptr(aq), ptr(a_sc), ptr(wq), ptr(w_sc), ptr(out), ptr(bias), ptr(lscale), ptr(res), M, N, K,
+                              aq.stride(0), wq.stride(0), out.stride(0), res.stride(0) if res is not None else 0, ACT[act],
+                              current_stream_ptr(aq.device)), "merv_gemm_mxfp8")
+    return out

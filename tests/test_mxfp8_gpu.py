@@ -1,0 +1,78 @@
+"""GPU: MXFP8 mode (BASELINE.json configs[4], "fp8 MFMA encoder GEMMs"). The checker is a torch emulation of OCP
+Microscaling -- per 32-element block: shared exponent floor(log2 amax) - 8, elements scaled, saturated to +-448 and
+rounded to nearest even into float8_e4m3fn -- and an fp32 matmul on the de-quantised values, which is what the scaled
+MFMA computes exactly (products of fp8 values and power-of-two scales are exact in fp32; only the summation order differs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def emulate_quantize(x: torch.Tensor):
+    rows, K = x.shape
+    v = x.float().reshape(rows, K // 32, 32)
+    amax = v.abs().amax(-1)
+    _, ex = torch.frexp(amax)  # amax = m * 2^ex, m in [0.5, 1)
+    e = (ex - 1 - 8).clamp(min=-127)
+    e = torch.where(amax == 0, torch.full_like(e, -127), e)
+    scaled = (v * torch.exp2(-e.float())[..., None]).clamp(-448, 448)
+    q = scaled.to(torch.float8_e4m3fn)
+    deq = q.float() * torch.exp2(e.float())[..., None]
+    return q.view(torch.uint8).reshape(rows, K), (e + 127).to(torch.uint8), deq.reshape(rows, K)
+
+
+@pytest.mark.parametrize("rows,K", [(64, 128), (1, 256), (257, 1024), (4112, 768)])
+def test_quantizer_matches_mx_emulation_bit_exact(dev, rows, K):
+    from merv_amd import ops
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 2)).to(torch.bfloat16)
+    x[0, :32] = 0  # an all-zero block
+    x[-1, -1] = 3.0e4  # a block dominated by one outlier
+    q_ref, s_ref, _ = emulate_quantize(x)
+    q, sc = ops.quantize_mxfp8(x.to(dev))
+    assert torch.equal(ops.mxfp8_scales_to_rows(sc, rows, K).cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+
+
+@pytest.mark.parametrize("M,N,K,act,use_res", [(256, 256, 512, "none", False), (300, 512, 1024, "gelu_erf", True),
+                                               (4112, 1024, 1024, "none", True), (2056, 768, 3072, "gelu_tanh", False),
+                                               (33000, 256, 768, "none", False)])
+def test_mx_gemm_vs_dequantised_fp32(dev, M, N, K, act, use_res):
+    from merv_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    ls = 0.5 + torch.rand(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16) if use_res else None
+    _, _, a_dq = emulate_quantize(a)
+    _, _, w_dq = emulate_quantize(w)
+    y = a_dq @ w_dq.t() + bias
+    if act == "gelu_erf":
+        y = F.gelu(y)
+    elif act == "gelu_tanh":
+        y = F.gelu(y, approximate="tanh")
+    ref = y * ls + (res.float() if use_res else 0)
+    aq, asc = ops.quantize_mxfp8(a.to(dev))
+    wq, wsc = ops.quantize_mxfp8(w.to(dev))
+    out = ops.gemm_mxfp8(aq, asc, wq, wsc, bias=bias.to(dev), act=act, lscale=ls.to(dev), res=res.to(dev) if use_res else None)
+    assert rel_l2(out, ref) < 6e-3, (M, N, K)  # bf16 output rounding, as for the bf16 GEMM
+    # and the price of the mode itself against the unquantised product (stated, not a parity bound): ~3-4 % relative L2
+    exact = a.float() @ w.float().t()
+    plain = ops.gemm_mxfp8(aq, asc, wq, wsc)
+    err = rel_l2(plain, exact)
+    assert 5e-3 < err < 6e-2, err
+
+
+def test_mx_argument_checks(dev):
+    from merv_amd import ops
+    a = torch.zeros(64, 384, dtype=torch.bfloat16, device=dev)
+    aq, asc = ops.quantize_mxfp8(a)
+    wq, wsc = ops.quantize_mxfp8(torch.zeros(256, 384, dtype=torch.bfloat16, device=dev))
+    with pytest.raises(ValueError):
+        ops.gemm_mxfp8(aq, asc, wq, wsc)  # K = 384 is not a multiple of 256
+    with pytest.raises(ValueError):
+        ops.quantize_mxfp8(torch.zeros(8, 96, dtype=torch.bfloat16, device=dev))  # K % 128
