@@ -182,6 +182,15 @@ int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M,
  * merv_gemm_mxfp8: C[M,N] bf16 = epilogue(A8 . W8^T), same epilogue arguments as merv_gemm_bf16 (bias, activation,
  *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
  */
+/*
+ * Encoder in MXFP8 mode: the four GEMMs of every block (qkv, attention out-projection, fc1, fc2) run on MXFP8 operands;
+ * LayerNorm, attention, the temporal sub-block, the patch embedding and the residual stream stay bf16. The library
+ * quantises the block weights it was given at merv_encoder_create into `buf` (merv_encoder_mxfp8_bytes(enc) bytes,
+ * 256-byte aligned, owned by the caller for the encoder's lifetime). Call merv_encoder_workspace_bytes AFTER enabling:
+ * the workspace grows by the quantised activation buffer. dim and mlp_dim must be multiples of 256 (>= 512).
+ */
+size_t merv_encoder_mxfp8_bytes(const merv_encoder *enc);
+int merv_encoder_enable_mxfp8(merv_encoder *enc, void *buf, size_t bytes, void *stream);
 size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K);
 int merv_quantize_mxfp8(const void *x, int32_t rows, int32_t K, int32_t ld, void *q, void *scales, void *stream);
 int merv_gemm_mxfp8(const void *A8, const void *scale_a, const void *W8, const void *scale_w, void *C, const float *bias,

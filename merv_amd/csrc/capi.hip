@@ -36,10 +36,16 @@ extern "C" int merv_abi_version(void) { return MERV_ABI_VERSION; }
         }                                                                               \
     } while (0)
 
+struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + block scales)
+    const uint8_t *qkv_q, *qkv_s, *proj_q, *proj_s, *fc1_q, *fc1_s, *fc2_q, *fc2_s;
+};
+
 struct merv_encoder {
     merv_encoder_desc d;
     merv_encoder_weights w;
     std::vector<merv_layer_weights> layers;
+    bool mx = false;            // MXFP8 mode enabled (merv_encoder_enable_mxfp8)
+    std::vector<MxLayer> mxl;
     // derived geometry
     int hp;        // patches per side
     int P;         // patch tokens per sequence
@@ -108,6 +114,8 @@ extern "C" int32_t merv_encoder_num_patches(const merv_encoder* enc) { return en
 namespace {
 struct Workspace {
     bf16_t *x, *y, *qkv, *h;
+    uint8_t *aq, *asc;  // MXFP8 mode: quantised [M, dim] GEMM input (LayerNorm / attention output) and its block scales
+    uint8_t *hq, *hsc;  // MXFP8 mode: quantised [M, mlp_dim] MLP hidden activations, written by fc1's epilogue
     size_t total;
 };
 Workspace carve(const merv_encoder* e, int batch, char* base) {
@@ -126,10 +134,57 @@ Workspace carve(const merv_encoder* e, int batch, char* base) {
     w.y = take(M * D * 2);
     w.qkv = take(M * 3 * D * 2);
     w.h = take(M * hcols * 2);
+    w.aq = w.asc = w.hq = w.hsc = nullptr;
+    if (e->mx) {
+        w.aq = (uint8_t*)take(M * D);
+        w.asc = (uint8_t*)take(mx_scale_bytes((int)M, (int)D));
+        w.hq = (uint8_t*)take(M * e->d.mlp_dim);
+        w.hsc = (uint8_t*)take(mx_scale_bytes((int)M, e->d.mlp_dim));
+    }
     w.total = off;
     return w;
 }
 }  // namespace
+
+// ---- MXFP8 mode of the encoder blocks (BASELINE.json configs[4]) ----
+static size_t mx_weight_bytes(int N, int K) { return align_up((size_t)N * K, 256) + align_up(mx_scale_bytes(N, K), 256); }
+
+extern "C" size_t merv_encoder_mxfp8_bytes(const merv_encoder* e) {
+    if (!e) return 0;
+    const int D = e->d.dim, H = e->d.mlp_dim;
+    return (size_t)e->d.layers * (mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D) + mx_weight_bytes(H, D) + mx_weight_bytes(D, H));
+}
+
+extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
+    MERV_CHECK(e && buf, "merv_encoder_enable_mxfp8: null argument");
+    const int D = e->d.dim, H = e->d.mlp_dim;
+    MERV_CHECK(D % 256 == 0 && D >= 512 && H % 256 == 0 && H >= 512, "merv_encoder_enable_mxfp8: dim and mlp_dim must be multiples of 256, >= 512");
+    MERV_CHECK(bytes >= merv_encoder_mxfp8_bytes(e), "merv_encoder_enable_mxfp8: buffer too small");
+    MERV_CHECK(((uintptr_t)buf & 255) == 0, "merv_encoder_enable_mxfp8: buffer must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    char* p = (char*)buf;
+    e->mxl.assign(e->d.layers, MxLayer{});
+    auto quant = [&](const void* w, int N, int K, const uint8_t*& q, const uint8_t*& sc) -> hipError_t {
+        uint8_t* qd = (uint8_t*)p;
+        uint8_t* sd = (uint8_t*)(p + align_up((size_t)N * K, 256));
+        p += mx_weight_bytes(N, K);
+        q = qd; sc = sd;
+        hipError_t err = hipMemsetAsync(sd, 0, mx_scale_bytes(N, K), s);  // padding rows of the last 64-row group
+        if (err != hipSuccess) return err;
+        MxQuantArgs a{(const bf16_t*)w, qd, sd, N, K, K};
+        return launch_mx_quantize(a, s);
+    };
+    for (int i = 0; i < e->d.layers; ++i) {
+        const merv_layer_weights& L = e->layers[i];
+        MxLayer& m = e->mxl[i];
+        MERV_HIP(quant(L.qkv_w, 3 * D, D, m.qkv_q, m.qkv_s));
+        MERV_HIP(quant(L.proj_w, D, D, m.proj_q, m.proj_s));
+        MERV_HIP(quant(L.fc1_w, H, D, m.fc1_q, m.fc1_s));
+        MERV_HIP(quant(L.fc2_w, D, H, m.fc2_q, m.fc2_s));
+    }
+    e->mx = true;
+    return 0;
+}
 
 extern "C" size_t merv_encoder_workspace_bytes(const merv_encoder* enc, int32_t batch) {
     if (!enc || batch <= 0) return 0;
@@ -182,6 +237,17 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         }
     }
 
+    // MXFP8 mode. The GEMM inputs arrive quantised from their producers where the producer is ours to change: both
+    // LayerNorms write e4m3 + block scales directly, fc1's epilogue writes fc2's input; only the attention output
+    // (bf16 from the attention kernel) takes a separate quantisation pass.
+    const int mx_groups = (M + 63) / 64;
+    auto mx_gemm = [&](GemmArgs g, const uint8_t* aq, const uint8_t* asc, const uint8_t* wq, const uint8_t* wsc) -> hipError_t {
+        g.A = (const bf16_t*)aq; g.lda = g.K;
+        g.W = (const bf16_t*)wq; g.ldw = g.K;
+        g.mx_scale_a = asc; g.mx_scale_w = wsc; g.mx_groups_a = mx_groups; g.mx_groups_w = g.N / 64;
+        return launch_gemm_mx(g, s);
+    };
+
     // ---- transformer blocks ----
     for (int li = 0; li < d.layers; ++li) {
         const merv_layer_weights& L = e->layers[li];
@@ -199,23 +265,38 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         }
         {
             LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
+            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
             MERV_HIP(launch_layernorm(ln, s));
             GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
-            MERV_HIP(launch_gemm(q, s));
+            if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
+            else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
-            MERV_HIP(launch_gemm(o, s));
+            if (e->mx) {
+                MxQuantArgs qa{ws.y, ws.aq, ws.asc, M, D, D};
+                MERV_HIP(launch_mx_quantize(qa, s));
+                MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
+            } else {
+                MERV_HIP(launch_gemm(o, s));
+            }
         }
         {
             LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
+            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
             MERV_HIP(launch_layernorm(ln, s));
             GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
-            MERV_HIP(launch_gemm(f1, s));
+            if (e->mx) {
+                f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups;
+                MERV_HIP(mx_gemm(f1, ws.aq, ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
+            } else {
+                MERV_HIP(launch_gemm(f1, s));
+            }
             GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
-            MERV_HIP(launch_gemm(f2, s));
+            if (e->mx) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
+            else MERV_HIP(launch_gemm(f2, s));
         }
     }
 

@@ -130,4 +130,39 @@ MERV_DEVICE int xcd_remap(int orig, int nwg) {
     return base + (orig >> 3);
 }
 
+
+// ---- MXFP8 (OCP Microscaling, e4m3 elements, E8M0 scale per 32 consecutive k) helpers shared by the quantiser, the
+// LayerNorm kernel and the GEMM epilogue. A 32-element block is held by 4 consecutive lanes, 8 elements each. ----
+MERV_DEVICE int mx_shared_exponent(float amax) {  // floor(log2(amax)) - 8, clamped to the E8M0 range
+    int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+    return e < -127 ? -127 : e;
+}
+MERV_DEVICE uint32_t mx_pack4(float a0, float a1, float a2, float a3, float inv) {
+    a0 = fminf(fmaxf(a0 * inv, -448.f), 448.f);
+    a1 = fminf(fmaxf(a1 * inv, -448.f), 448.f);
+    a2 = fminf(fmaxf(a2 * inv, -448.f), 448.f);
+    a3 = fminf(fmaxf(a3 * inv, -448.f), 448.f);
+    int packed = 0;
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, packed, false);
+    packed = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, packed, true);
+    return (uint32_t)packed;
+}
+// 8 values of this lane (one quarter of a block; lanes l, l^1, l^2, l^3 hold the block): returns the 8 e4m3 bytes and
+// the block's biased exponent byte. Every lane of the 4-lane group must call it (cross-lane max).
+MERV_DEVICE u32x2 mx_quantize8(const float* v, int& scale_byte) {
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const int e = mx_shared_exponent(amax);
+    const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+    scale_byte = e + 127;
+    return u32x2{mx_pack4(v[0], v[1], v[2], v[3], inv), mx_pack4(v[4], v[5], v[6], v[7], inv)};
+}
+// byte offset of the scale of (row, kblock) in the GEMM's lane-order layout [kblock/4][row/64][(kblock%4)*16 + row%16][(row%64)/16]
+MERV_DEVICE size_t mx_scale_offset(int row, int kb, int groups) {
+    return ((((size_t)(kb >> 2) * groups + (row >> 6)) * 64 + (kb & 3) * 16 + (row & 15)) << 2) + ((row & 63) >> 4);
+}
+
 }  // namespace merv

@@ -138,7 +138,21 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 for (int q = 0; q < 4; ++q)
                     t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
             }
-            if (valid[it]) *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+            if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (4 lanes = one 32-column block of the row)
+                float r[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { r[2 * q] = bflo(t[q]); r[2 * q + 1] = bfhi(t[q]); }
+                int sb;
+                const u32x2 q8 = mx_quantize8(r, sb);
+                const int m = m0 + wr * WTM_FULL + part * WTM + (elane >> 3) + 8 * it;
+                const int col = wn0 + ec * 8;
+                if (valid[it]) {
+                    *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
+                    if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
+                }
+            } else if (valid[it]) {
+                *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+            }
         }
     }
 }

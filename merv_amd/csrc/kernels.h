@@ -23,6 +23,11 @@ struct GemmArgs {
     const void* mx_scale_a;  // E8M0 block scales of A, layout of mx_quantize (below)
     const void* mx_scale_w;
     int mx_groups_a, mx_groups_w;  // 64-row groups in each scale array (ceil(rows / 64))
+    // any launch: when mx_out_q is set the epilogue writes its (bf16-rounded) result as MXFP8 -- e4m3 [M, N] + block
+    // scales in the layout of mx_quantize -- instead of bf16 C (the next GEMM's quantised input, e.g. fc1 -> fc2)
+    uint8_t* mx_out_q;
+    uint8_t* mx_out_scales;
+    int mx_out_groups;
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s);
@@ -54,6 +59,11 @@ struct LayerNormArgs {
     int M, D;
     int add_div, add_mod;
     float eps;
+    // MXFP8 mode: when mx_q is set the normalised row is written as e4m3 + block scales (the layout mx_quantize
+    // produces) instead of bf16 y -- the consumer is an MXFP8 GEMM
+    uint8_t* mx_q;        // [M, D]
+    uint8_t* mx_scales;
+    int mx_groups;        // ceil(M / 64)
 };
 hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
 

@@ -28,28 +28,15 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(MxQuantArgs p) {
                 v[c * 8 + 2 * w + 1] = bfhi(raw[c][w]);
                 amax = fmaxf(amax, fmaxf(fabsf(v[c * 8 + 2 * w]), fabsf(v[c * 8 + 2 * w + 1])));
             }
-        // shared exponent: floor(log2(amax)) - 8, clamped to the E8M0 range; amax == 0 (or subnormal) -> smallest scale
-        int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
-        e = e < -127 ? -127 : e;
+        const int e = mx_shared_exponent(amax);  // amax == 0 (or subnormal) -> smallest scale
         const float inv = __uint_as_float((uint32_t)(127 - e) << 23);  // 2^-e, exponent field in [1, 254]
         uint32_t outw[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            float a0 = v[4 * w] * inv, a1 = v[4 * w + 1] * inv, a2 = v[4 * w + 2] * inv, a3 = v[4 * w + 3] * inv;
-            a0 = fminf(fmaxf(a0, -448.f), 448.f);
-            a1 = fminf(fmaxf(a1, -448.f), 448.f);
-            a2 = fminf(fmaxf(a2, -448.f), 448.f);
-            a3 = fminf(fmaxf(a3, -448.f), 448.f);
-            int packed = 0;
-            packed = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, packed, false);
-            packed = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, packed, true);
-            outw[w] = (uint32_t)packed;
-        }
+        for (int w = 0; w < 8; ++w) outw[w] = mx_pack4(v[4 * w], v[4 * w + 1], v[4 * w + 2], v[4 * w + 3], inv);
         uint8_t* dst = p.q + (size_t)row * p.K + kb * 32;
         *(u32x4*)dst = u32x4{outw[0], outw[1], outw[2], outw[3]};
         *(u32x4*)(dst + 16) = u32x4{outw[4], outw[5], outw[6], outw[7]};
-        const size_t so = ((((size_t)(kb >> 2) * groups + (row >> 6)) * 64 + (kb & 3) * 16 + (row & 15)) << 2) + ((row & 63) >> 4);
-        p.scales[so] = (uint8_t)(e + 127);
+        p.scales[mx_scale_offset(row, kb, groups)] = (uint8_t)(e + 127);
     }
 }
 

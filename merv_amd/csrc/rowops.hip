@@ -75,7 +75,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
             float o[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * g[j] + b[j];
-            *(u32x4*)(yr + c * 8) = pack8f(o);
+            const u32x4 packed = pack8f(o);
+            if (p.mx_q) {  // uniform; chunks come in aligned groups of 4 lanes (D % 32 == 0), so the cross-lane max is safe
+                float r[8];
+                unpack8(packed, r);  // quantise the bf16-rounded values, as the stand-alone quantiser would
+                int sb;
+                const u32x2 q8 = mx_quantize8(r, sb);
+                *(u32x2*)(p.mx_q + (size_t)row * p.D + c * 8) = q8;
+                if ((lane & 3) == 0) p.mx_scales[mx_scale_offset(row, c >> 2, p.mx_groups)] = (uint8_t)sb;
+            } else {
+                *(u32x4*)(yr + c * 8) = packed;
+            }
         }
     }
 }

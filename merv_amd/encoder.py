@@ -169,6 +169,17 @@ class HipEncoder:
             self._lib.merv_encoder_destroy(h)
             self._handle = None
 
+    def enable_mxfp8(self) -> "HipEncoder":
+        """Switch the four block GEMMs to MXFP8 operands (BASELINE.json configs[4]; include/merv_hip.h). The library
+        quantises the weights into a buffer this object keeps alive. Not the default: trades the bf16 tolerance for speed."""
+        need = self._lib.merv_encoder_mxfp8_bytes(self._handle)
+        self._mx_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(self._lib.merv_encoder_enable_mxfp8(self._handle, ptr(self._mx_buf), need,
+                                                  torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_mxfp8")
+        self._ws = None  # the workspace grows
+        self.mxfp8 = True
+        return self
+
     def workspace(self, batch: int) -> torch.Tensor:
         need = self._lib.merv_encoder_workspace_bytes(self._handle, batch)
         if self._ws is None or self._ws.numel() < need:

@@ -155,17 +155,37 @@ def act_fn(name: str, x: torch.Tensor) -> torch.Tensor:
     raise ValueError(name)
 
 
-def _mhsa(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, heads: int) -> torch.Tensor:
+def mx_quantize_dequantize(x: torch.Tensor) -> torch.Tensor:
+    """OCP Microscaling FP8 (e4m3, 32-element blocks along the last dim, E8M0 shared exponent floor(log2 amax) - 8,
+    saturating round-to-nearest-even) applied and undone: the values the MXFP8 mode's GEMMs multiply. No counterpart in
+    the reference (BASELINE.json configs[4] is this build's fp8 mode); used only to check that mode."""
+    shp = x.shape
+    v = x.float().reshape(-1, shp[-1] // 32, 32)
+    amax = v.abs().amax(-1)
+    _, ex = torch.frexp(amax)
+    e = (ex - 1 - 8).clamp(min=-127)
+    e = torch.where(amax == 0, torch.full_like(e, -127), e)
+    sc = torch.exp2(e.float())[..., None]
+    q = (v / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    return (q * sc).reshape(shp)
+
+
+def mx_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """F.linear on MXFP8-quantised input and weight (the input first rounded to bf16, as the HIP path stores it)."""
+    return F.linear(mx_quantize_dequantize(x.to(torch.bfloat16).float()), mx_quantize_dequantize(w.to(torch.bfloat16).float()), b)
+
+
+def _mhsa(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, heads: int, linear=F.linear) -> torch.Tensor:
     """softmax(q k^T / sqrt(d)) v with fused qkv weights; x [N, L, D].
     timm Attention.forward; HF CLIPAttention (q*scale, softmax, no mask; modeling_video.py:98,168); HF VivitSelfAttention."""
     N, L, D = x.shape
     hd = D // heads
-    qkv = F.linear(x, qkv_w, qkv_b).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = linear(x, qkv_w, qkv_b).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = (q @ k.transpose(-1, -2)) * (hd**-0.5)
     att = att.softmax(dim=-1)
     o = (att @ v).transpose(1, 2).reshape(N, L, D)
-    return F.linear(o, proj_w, proj_b)
+    return linear(o, proj_w, proj_b)
 
 
 def encoder_embed(pix: torch.Tensor, cfg: EncoderCfg, W: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -199,8 +219,9 @@ def encoder_embed(pix: torch.Tensor, cfg: EncoderCfg, W: Dict[str, torch.Tensor]
     return emb
 
 
-def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
+def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor], mx: bool = False) -> torch.Tensor:
+    """(mx=True: qkv / attention-out / fc1 / fc2 through mx_linear -- the MXFP8 mode's emulation; the temporal sub-block
+    stays as is.) One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
     CLIPEncoderLayer with its temporal sub-block first (modeling_video.py:133-179)."""
     D = cfg.dim
     if cfg.temporal_frames:
@@ -216,19 +237,20 @@ def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor])
         h = F.layer_norm(h, (D,), Lw["t_ln_w"], Lw["t_ln_b"], cfg.ln_eps)  # :147
         h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads)
         x = residual + h.reshape(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)  # :155
+    lin = mx_linear if mx else F.linear
     h = F.layer_norm(x, (D,), Lw["ln1_w"], Lw["ln1_b"], cfg.ln_eps)
-    h = _mhsa(h, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads)
+    h = _mhsa(h, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads, lin)
     if cfg.layerscale:
         h = h * Lw["ls1"]
     x = x + h
     h = F.layer_norm(x, (D,), Lw["ln2_w"], Lw["ln2_b"], cfg.ln_eps)
-    h = F.linear(act_fn(cfg.act, F.linear(h, Lw["fc1_w"], Lw["fc1_b"])), Lw["fc2_w"], Lw["fc2_b"])
+    h = lin(act_fn(cfg.act, lin(h, Lw["fc1_w"], Lw["fc1_b"])), Lw["fc2_w"], Lw["fc2_b"])
     if cfg.layerscale:
         h = h * Lw["ls2"]
     return x + h
 
 
-def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict) -> torch.Tensor:
+def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = False) -> torch.Tensor:
     """VideoBackbone.forward -> [B, num_patches, D]:
     languagebind/__init__.py:79-103 (hidden_states[-2], 'noclass'), dinov2_video.py:132-154 (n={L-2}, prefix
     stripped, no final norm), vivit.py:100-118 (last layer + final LayerNorm, drop cls, (B,16,14,14,C)),
@@ -236,7 +258,7 @@ def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict) -> torch.Tensor
     B = pix.shape[0]
     x = encoder_embed(pix, cfg, W)
     for li in range(cfg.layers):
-        x = encoder_block(x, cfg, W["layers"][li])
+        x = encoder_block(x, cfg, W["layers"][li], mx)
     if cfg.final_ln:
         x = F.layer_norm(x, (cfg.dim,), W["final_ln_w"], W["final_ln_b"], cfg.ln_eps)
     x = x[:, cfg.prefix_tokens:]
