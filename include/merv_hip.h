@@ -183,8 +183,9 @@ int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M,
  *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
  */
 /*
- * Encoder in MXFP8 mode: the four GEMMs of every block (qkv, attention out-projection, fc1, fc2) run on MXFP8 operands;
- * LayerNorm, attention, the temporal sub-block, the patch embedding and the residual stream stay bf16. The library
+ * Encoder in MXFP8 mode: the GEMMs of every block (qkv, attention out-projection, fc1, fc2, and LanguageBind's temporal
+ * qkv / out-projection) run on MXFP8 operands; LayerNorm statistics, attention, the patch embedding and the residual
+ * stream stay bf16 / fp32. The library
  * quantises the block weights it was given at merv_encoder_create into `buf` (merv_encoder_mxfp8_bytes(enc) bytes,
  * 256-byte aligned, owned by the caller for the encoder's lifetime). Call merv_encoder_workspace_bytes AFTER enabling:
  * the workspace grows by the quantised activation buffer. dim and mlp_dim must be multiples of 256 (>= 512).

@@ -293,7 +293,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         for (int it = 0; it < 4; ++it) {
             const int rr = (lane >> 3) + 8 * it, c = lane & 7;
             const u32x4 v = *(const u32x4*)(stg + rr * 128 + ((c ^ (rr & 7)) * 16));
-            if (q0 + rr < L) *(u32x4*)(p.out + ((size_t)seq * L + q0 + rr) * D + head * HD + c * 8) = v;
+            if (p.mx_q) {  // uniform: lanes c = 4b .. 4b+3 hold the 32-column block b of this head's row
+                float f[8];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { f[2 * w] = bflo(v[w]); f[2 * w + 1] = bfhi(v[w]); }
+                int sb;
+                const u32x2 q8 = mx_quantize8(f, sb);
+                if (q0 + rr < L) {
+                    const int row = seq * L + q0 + rr, col = head * HD + c * 8;
+                    *(u32x2*)(p.mx_q + (size_t)row * D + col) = q8;
+                    if ((c & 3) == 0) p.mx_scales[mx_scale_offset(row, col >> 5, p.mx_groups)] = (uint8_t)sb;
+                }
+            } else if (q0 + rr < L) {
+                *(u32x4*)(p.out + ((size_t)seq * L + q0 + rr) * D + head * HD + c * 8) = v;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads returned before the next tile overwrites
     }
@@ -400,7 +413,34 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalAttnArgs p) 
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
         }
     }
-    if (pid0 + myp < NP) {
+    if (p.mx_q) {
+        // MXFP8 output: the 32-column block `db` of a row is this lane's 16 values (4 per i) and the 16 of lane ^ 32
+        const bool ok = pid0 + myp < NP;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            float f[16];
+            float amax = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w0 = pack2bf(oacc[db][4 * i + 0], oacc[db][4 * i + 1]);  // quantise the bf16-rounded values
+                const uint32_t w1 = pack2bf(oacc[db][4 * i + 2], oacc[db][4 * i + 3]);
+                f[4 * i] = bflo(w0); f[4 * i + 1] = bfhi(w0); f[4 * i + 2] = bflo(w1); f[4 * i + 3] = bfhi(w1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(f[4 * i + j]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const int e = mx_shared_exponent(amax);
+            const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+            if (ok) {
+                const int col0 = head * HD + db * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *(uint32_t*)(p.mx_q + (size_t)my_row * D + col0 + 8 * i + 4 * h) =
+                        mx_pack4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3], inv);
+                if (h == 0) p.mx_scales[mx_scale_offset((int)my_row, col0 >> 5, p.mx_groups)] = (uint8_t)(e + 127);
+            }
+        }
+    } else if (pid0 + myp < NP) {
         bf16_t* orow = p.out + my_row * D + head * HD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)

@@ -38,6 +38,7 @@ extern "C" int merv_abi_version(void) { return MERV_ABI_VERSION; }
 
 struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + block scales)
     const uint8_t *qkv_q, *qkv_s, *proj_q, *proj_s, *fc1_q, *fc1_s, *fc2_q, *fc2_s;
+    const uint8_t *tqkv_q, *tqkv_s, *tproj_q, *tproj_s;  // LanguageBind temporal sub-block (null otherwise)
 };
 
 struct merv_encoder {
@@ -152,7 +153,9 @@ static size_t mx_weight_bytes(int N, int K) { return align_up((size_t)N * K, 256
 extern "C" size_t merv_encoder_mxfp8_bytes(const merv_encoder* e) {
     if (!e) return 0;
     const int D = e->d.dim, H = e->d.mlp_dim;
-    return (size_t)e->d.layers * (mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D) + mx_weight_bytes(H, D) + mx_weight_bytes(D, H));
+    size_t per_layer = mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D) + mx_weight_bytes(H, D) + mx_weight_bytes(D, H);
+    if (e->d.temporal_frames > 0) per_layer += mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D);
+    return (size_t)e->d.layers * per_layer;
 }
 
 extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
@@ -181,6 +184,10 @@ extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t byte
         MERV_HIP(quant(L.proj_w, D, D, m.proj_q, m.proj_s));
         MERV_HIP(quant(L.fc1_w, H, D, m.fc1_q, m.fc1_s));
         MERV_HIP(quant(L.fc2_w, D, H, m.fc2_q, m.fc2_s));
+        if (e->d.temporal_frames > 0) {
+            MERV_HIP(quant(L.t_qkv_w, 3 * D, D, m.tqkv_q, m.tqkv_s));
+            MERV_HIP(quant(L.t_proj_w, D, D, m.tproj_q, m.tproj_s));
+        }
     }
     e->mx = true;
     return 0;
@@ -237,9 +244,8 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         }
     }
 
-    // MXFP8 mode. The GEMM inputs arrive quantised from their producers where the producer is ours to change: both
-    // LayerNorms write e4m3 + block scales directly, fc1's epilogue writes fc2's input; only the attention output
-    // (bf16 from the attention kernel) takes a separate quantisation pass.
+    // MXFP8 mode. Every GEMM input arrives quantised from its producer: the LayerNorms, the attention kernels and fc1's
+    // epilogue write e4m3 + block scales directly (no separate quantisation pass, no bf16 copy of those tensors).
     const int mx_groups = (M + 63) / 64;
     auto mx_gemm = [&](GemmArgs g, const uint8_t* aq, const uint8_t* asc, const uint8_t* wq, const uint8_t* wsc) -> hipError_t {
         g.A = (const bf16_t*)aq; g.lda = g.K;
@@ -254,14 +260,18 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         if (d.temporal_frames > 0) {
             // x += temporal_embedding[t]; x += out_proj(temporal_attn(LN_t(x)))   (modeling_video.py:133-155)
             LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
+            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
             MERV_HIP(launch_layernorm(ln, s));
             GemmArgs q = gemm_args(ws.y, D, L.t_qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.t_qkv_b, ACT_NONE);
-            MERV_HIP(launch_gemm(q, s));
+            if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
+            else MERV_HIP(launch_gemm(q, s));
             TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
+            if (e->mx) { ta.mx_q = ws.aq; ta.mx_scales = ws.asc; ta.mx_groups = mx_groups; }
             MERV_HIP(launch_temporal_attention(ta, s));
             GemmArgs o = gemm_args(ws.y, D, L.t_proj_w, D, ws.x, D, M, D, L.t_proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D;
-            MERV_HIP(launch_gemm(o, s));
+            if (e->mx) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
+            else MERV_HIP(launch_gemm(o, s));
         }
         {
             LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
@@ -271,16 +281,12 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
             if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
             else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
+            if (e->mx) { at.mx_q = ws.aq; at.mx_scales = ws.asc; at.mx_groups = mx_groups; }
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
-            if (e->mx) {
-                MxQuantArgs qa{ws.y, ws.aq, ws.asc, M, D, D};
-                MERV_HIP(launch_mx_quantize(qa, s));
-                MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
-            } else {
-                MERV_HIP(launch_gemm(o, s));
-            }
+            if (e->mx) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
+            else MERV_HIP(launch_gemm(o, s));
         }
         {
             LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};

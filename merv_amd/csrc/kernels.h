@@ -74,6 +74,11 @@ struct AttnArgs {
     bf16_t* out;        // [nseq*L, D]
     int nseq, L, heads, D;
     float scale;        // 1/sqrt(head_dim)
+    // MXFP8 mode: when mx_q is set the output goes out as e4m3 [rows, D] + block scales (layout of mx_quantize)
+    // instead of bf16 `out` -- it is the quantised input of the out-projection GEMM
+    uint8_t* mx_q;
+    uint8_t* mx_scales;
+    int mx_groups;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
@@ -84,6 +89,9 @@ struct TemporalAttnArgs {
     bf16_t* out;        // [nclips*t*ntok, D]
     int nclips, t, ntok, heads, D;
     float scale;
+    uint8_t* mx_q;      // MXFP8 mode, as in AttnArgs
+    uint8_t* mx_scales;
+    int mx_groups;
 };
 hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s);
 

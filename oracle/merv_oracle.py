@@ -220,10 +220,11 @@ def encoder_embed(pix: torch.Tensor, cfg: EncoderCfg, W: Dict[str, torch.Tensor]
 
 
 def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor], mx: bool = False) -> torch.Tensor:
-    """(mx=True: qkv / attention-out / fc1 / fc2 through mx_linear -- the MXFP8 mode's emulation; the temporal sub-block
-    stays as is.) One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
+    """(mx=True: every GEMM of the block -- temporal qkv / out-projection, qkv, attention out-projection, fc1, fc2 --
+    through mx_linear: the MXFP8 mode's emulation.) One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
     CLIPEncoderLayer with its temporal sub-block first (modeling_video.py:133-179)."""
     D = cfg.dim
+    lin = mx_linear if mx else F.linear
     if cfg.temporal_frames:
         t = cfg.temporal_frames
         bt, n, d = x.shape
@@ -235,9 +236,8 @@ def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor],
         residual = x  # :144
         h = x.reshape(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
         h = F.layer_norm(h, (D,), Lw["t_ln_w"], Lw["t_ln_b"], cfg.ln_eps)  # :147
-        h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads)
+        h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads, lin)
         x = residual + h.reshape(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)  # :155
-    lin = mx_linear if mx else F.linear
     h = F.layer_norm(x, (D,), Lw["ln1_w"], Lw["ln1_b"], cfg.ln_eps)
     h = _mhsa(h, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads, lin)
     if cfg.layerscale:
