@@ -269,7 +269,8 @@ def main():
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
                        "encoder_streams": "sequential" if args.sequential else "concurrent",
                        "parallelism": "single GPU" if world == 1 else f"(encoder,video) units over {world} GPUs, {args.exchange}",
-                       "path_tflops": round(path_tflops, 1), "path_frac_of_mfma_peak": round(path_tflops / PEAK_BF16_TFLOPS, 4),
+                       "path_tflops": round(path_tflops, 1),
+                       "path_frac_of_mfma_peak": round(path_tflops / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),
                        "flops_per_video_T": round(flops_video / 1e12, 3)},
             "roofline": roof,
         }
