@@ -233,8 +233,9 @@ int merv_preprocess_pil(const void *frames_u8, int32_t T, int32_t H, int32_t W, 
 int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t flip,
                                  const float *mean3, const float *std3, void *out_pixels, int32_t out_dtype, void *stream);
 
-/* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128,
- * 4 / 5: the staggered forms of 3 / 2; second byte: tile-order group size, 0 = default). */
+/* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128 two-deep ring, 3: 256x128,
+ * 4: 256x128 with staggered half-blocks, 6: 128x128 four-deep ring, 7: 256x256 eight-phase where the shape allows it;
+ * second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
 
 /*

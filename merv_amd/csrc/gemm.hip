@@ -722,10 +722,8 @@ int plan_split(const GemmArgs& a) {
 template <int ACT>
 hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
     switch (choose_variant(a)) {
-        case 2: return launch_cfg<256, 256, 2, 4, 2, false, ACT>(a, s);
         case 3: return launch_cfg<256, 128, 4, 2, 3, false, ACT>(a, s);
         case 4: return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
-        case 5: return launch_cfg<256, 256, 2, 4, 2, true, ACT>(a, s);
         case 6: return launch_cfg<128, 128, 2, 2, 4, false, ACT>(a, s);
         case 7:
             if (a.N % 256 == 0 && (a.K / BK) % 2 == 0 && a.K / BK >= 4) return launch_8phase<ACT>(a, s);
@@ -750,7 +748,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
         const double rows_out = a.out_group > 0 ? ((double)(a.M / a.out_group) + 1) * a.out_stride + a.out_off : (double)a.M;
         if (rows_out * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
     }
-    if (g_gemm_variant == 2 && a.N % 256 != 0) return hipErrorInvalidValue;
     ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
                  2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2 : 1)));
     auto dispatch = [&](const GemmArgs& g, bool eight_phase) -> hipError_t {

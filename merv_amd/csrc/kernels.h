@@ -44,8 +44,8 @@ struct MxQuantArgs {
 };
 hipError_t launch_mx_quantize(const MxQuantArgs& a, hipStream_t s);
 size_t mx_scale_bytes(int rows, int K);
-void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128, 2: 256x256, 3: 256x128, 4/5: staggered 256x128 / 256x256, 6: 128x128 4-deep ring,
-                               // 7: 256x256 eight-phase;
+void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128 2-deep ring, 3: 256x128, 4: 256x128 staggered, 6: 128x128 4-deep ring,
+                               // 7: 256x256 eight-phase (2 and 5 were the retired two-stage 256x256 forms);
                                // second byte: tile-order group size override (tuning / tests)
 
 // Row LayerNorm (fp32 statistics), optional fused "x += add[(row / add_div) % add_mod]" written back in place

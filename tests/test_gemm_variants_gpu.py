@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 # variant 0 = automatic choice, incl. the split between the eight-phase kernel (complete rounds) and a smaller-tile
 # launch for the remaining rows; 7 = eight-phase forced (needs N % 256 == 0 and an even number >= 4 of K-tiles)
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (300, 256, 128), (4112, 1024, 1024), (33000, 768, 192), (70000, 256, 64),
                                    (33000, 768, 256), (513, 512, 640), (66000, 512, 256), (25096, 2304, 768)])
 def test_variant(dev, variant, M, N, K):
