@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; useful at --batch 1)")
     ap.add_argument("--mxfp8", action="store_true",
                     help="BASELINE.json configs[4] variant: block GEMMs on MXFP8 operands (NOT the headline bf16 metric; "
                          "dtype is reported as mxfp8 and the roofline peak as the dense fp8 peak)")
@@ -183,9 +184,10 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world == 1 and not force_dist:
         pixels = synth_pixels(specs, B, device, seed=rank)
+        replay = path.capture(pixels) if args.graph else None
 
         def step():
-            return path.forward(pixels)
+            return replay() if (replay is not None and path.concurrent) else path.forward(pixels)
     else:
         from merv_amd.distributed import DistributedVisualPath
         dpath = DistributedVisualPath(path, [s.flops_per_video() for s in specs], world, rank, B, exchange=args.exchange)
@@ -267,7 +269,7 @@ def main():
                                     "merv-frozen 4 frozen encoders bf16 inference, frames [16,16,32,16], 224px "
                                     "(BASELINE.json configs[1])"),
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
-                       "encoder_streams": "sequential" if args.sequential else "concurrent",
+                       "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if args.graph else ""),
                        "parallelism": "single GPU" if world == 1 else f"(encoder,video) units over {world} GPUs, {args.exchange}",
                        "path_tflops": round(path_tflops, 1),
                        "path_frac_of_mfma_peak": round(path_tflops / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         __syncthreads();
         if (t + 1 < ntiles) load_tile(kv0 + 64);
         const bool tail = kv0 + 64 > L;
+        // 257 = 4 * 64 + 1 and 3137 = 49 * 64 + 1: in the last tile of those sequences keys 32..63 are all padding;
+        // their score MFMAs, exponentials and P.V MFMAs are skipped (wave-uniform)
+        const bool both_halves = kv0 + 32 < L;
 
         // ---- S^T = K Q^T (keys on rows, queries on lanes). With <= 2 query tiles per wave all of them are issued
         //      first, so the MFMAs of tile qi+1 run in the matrix pipe under the softmax VALU work of tile qi; with 3
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         auto scores = [&](int qi, f32x16(&sa)[2]) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
                 const int key = kb * 32 + r;
                 const char* krow = k_lds + key * KROW;
                 const int sw = kswz(key);
@@ -227,24 +231,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key >= L) sa[kb][i] = -INFINITY;
+                        if (key >= L) sa[kb][i] = -INFINITY;  // (covers the skipped half too: its registers are stale)
                     }
             }
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[kb][i]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
             const float m_new = fmaxf(m_run[qi], mx);
             float psum = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float e = fast_exp2(fmaf(sa[kb][i], sc, -m_new));
                     sa[kb][i] = e;
                     psum += e;
                 }
+            }
             if (!__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
                 const float alpha = fast_exp2(m_run[qi] - m_new);
                 l_run[qi] *= alpha;
@@ -256,7 +264,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 
             // ---- O^T += V^T P^T ----
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 pf = pack8(sa[kb], 8 * s2);
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                         oacc[qi][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qi][db], 0, 0, 0);
                     }
                 }
+            }
         }
     }
 

@@ -69,3 +69,33 @@ def test_merv_full_reduced_depth_through_registry(dev):
     assert fused.shape == (1, 1024, 1024)
     assert (w.cpu() - wref).abs().max() < 5e-3
     assert rel_l2(fused, ref) < 2e-2
+
+
+def test_hipgraph_replay_matches_eager(dev):
+    """MervVisualPath.capture: the replayed graph (four encoder chains forked onto side streams inside the capture) gives
+    bit-identical fused tokens, and follows new pixel values copied into its static inputs."""
+    import bench
+    from merv_amd.encoder import merv_full_specs
+    import dataclasses
+    from merv_amd.backbones import random_weights
+    from merv_amd.projector import CrossAttentionAdapterLearnableQuery
+    from merv_amd.visual_path import MervVisualPath
+    specs = [dataclasses.replace(s, layers=1) for s in merv_full_specs()]
+    torch.manual_seed(0)
+    enc_w = [random_weights(s, seed=i) for i, s in enumerate(specs)]
+    proj_w = [(torch.randn(256, s.dim) * 0.02, torch.zeros(256)) for s in specs]
+    fusion = CrossAttentionAdapterLearnableQuery(embed_dim=96, llm_dim=256, token_length=1024, averagetoken=True)
+    path = MervVisualPath(specs, enc_w, proj_w, fusion, dev)
+    g = torch.Generator().manual_seed(3)
+    pix = [torch.randn(s.pixel_shape(1), generator=g).to(dev) for s in specs]
+    pix2 = [torch.randn(s.pixel_shape(1), generator=g).to(dev) for s in specs]
+    eager, w = path.forward(pix)
+    eager, w = eager.clone(), w.clone()
+    eager2 = path.forward(pix2)[0].clone()
+    replay = path.capture(pix)
+    f, wr = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(f, eager) and torch.equal(wr, w)
+    f2, _ = replay(pix2)
+    torch.cuda.synchronize()
+    assert torch.equal(f2, eager2) and not torch.equal(eager2, eager)
