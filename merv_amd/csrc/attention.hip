@@ -487,9 +487,16 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (a.nseq <= 0 || a.L <= 0) return hipSuccess;
     if (a.D != a.heads * HD) return hipErrorInvalidValue;
     ProfScope ps(PROF_ATTN, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
-    // block shape: least padded query tiles; 257- / 261-token sequences are exactly 9 tiles = 3 waves x 3
+    // block shape. Short sequences: least padded query tiles -- 257- / 261-token sequences are exactly 9 tiles = 3 waves
+    // x 3, streamed once per (sequence, head). Long sequences (ViViT, 3137 tokens = 99 tiles): 4 waves x 2 even at 5 %
+    // more padded tiles, because with two tiles per wave both score products are issued before the first softmax, so
+    // the matrix pipe works under the softmax VALU stream (measured at B=8: 354 us vs 440-463 us per layer with 3 x 3).
     const int t32 = (a.L + 31) / 32;
+    static const char* force = getenv("MERV_ATTN_CFG");  // tuning hook: "33" or "42"
+    if (force && force[0] == '3') return launch_attn_cfg<3, 3>(a, s);
+    if (force && force[0] == '4') return launch_attn_cfg<4, 2>(a, s);
     if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
+    if (a.L >= 1024) return launch_attn_cfg<4, 2>(a, s);
     const int pad9 = (t32 + 8) / 9 * 9 - t32, pad8 = (t32 + 7) / 8 * 8 - t32;
     if (pad9 < pad8) return launch_attn_cfg<3, 3>(a, s);
     return launch_attn_cfg<4, 2>(a, s);
