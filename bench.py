@@ -242,7 +242,7 @@ def main():
                     traffic = per_step / (n.value / args.steps) if per_step else None  # per GEMM call, like `achieved`
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel (all tile configs, all launches of the step)",
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_8phase_kernel + gemm_bf16_kernel for the remaining rows (every GEMM call of the step)",
                     "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),
                     "traffic": None if args.mxfp8 else traffic,

@@ -92,3 +92,33 @@ def test_load_vid_errors(tmp_path, dev):
     (run / "encoders" / "dinov2-video-all-tokens.pt").unlink()
     with pytest.raises(FileNotFoundError):
         load_vid(run, llm_config=TINY_LLM, device=dev)  # never a silent random encoder
+
+
+def test_quick_start_script_shape(tmp_path, dev):
+    """The reference's scripts/quick_start.py, line for line, against a local run directory: `from merv import load_vid`,
+    `vidlm.to(device, dtype=bf16)`, prompt builder turns, `generate(video_path, prompt_text, num_frames=..., do_sample=...,
+    temperature=..., max_new_tokens=..., min_length=...)`. The video is a GIF (no decord here), the tokenizer a stand-in."""
+    import numpy as np
+    from PIL import Image
+    from merv import load_vid  # the alias package at the repo root
+
+    class Tok:  # callable tokenizer with decode(), the two things generate() uses
+        def __call__(self, text):
+            return [1] + [3 + (ord(c) % 200) for c in text][:20]
+
+        def decode(self, ids):
+            return " ".join(str(i) for i in ids)
+
+    run, *_ = _write_run(tmp_path, dev)
+    vidlm = load_vid(str(run), hf_token="unused", llm_config=TINY_LLM, tokenizer=Tok(), device=dev)
+    vidlm.to(dev, dtype=torch.bfloat16)
+    frames = [Image.fromarray(np.full((48, 64, 3), 25 * i, dtype=np.uint8)) for i in range(8)]
+    video_path = tmp_path / "clip.gif"
+    frames[0].save(video_path, save_all=True, append_images=frames[1:], duration=40, loop=0)
+    prompt_builder = vidlm.get_prompt_builder()
+    prompt_builder.add_turn(role="human", message="Describe what is happening in this video.")
+    prompt_text = prompt_builder.get_prompt()
+    assert prompt_text == "In: Describe what is happening in this video.\nOut:"
+    generated_text = vidlm.generate(str(video_path), prompt_text, num_frames=[4], do_sample=True, temperature=0.4,
+                                    max_new_tokens=5, min_length=1)
+    assert isinstance(generated_text, str) and 1 <= len(generated_text.split()) <= 5
