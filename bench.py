@@ -142,6 +142,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
     ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "units"],
+                    help="N > 1: 'dp' = every rank runs the whole path on its own videos (independent units, no data-path "
+                         "collective; the weak-scaling form of configs[1]); 'units' = (encoder, video) units placed across "
+                         "ranks with an RCCL exchange of projected tokens before fusion (configs[2]'s encoder sharding)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; useful at --batch 1)")
@@ -182,8 +186,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    if world == 1 and not force_dist:
-        pixels = synth_pixels(specs, B, device, seed=rank)
+    use_units = force_dist or (world > 1 and args.parallelism == "units")
+    if not use_units:
+        pixels = synth_pixels(specs, B, device, seed=rank)  # this rank's own videos
         replay = path.capture(pixels) if args.graph else None
 
         def step():
@@ -270,7 +275,9 @@ def main():
                                     "(BASELINE.json configs[1])"),
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
                        "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if args.graph else ""),
-                       "parallelism": "single GPU" if world == 1 else f"(encoder,video) units over {world} GPUs, {args.exchange}",
+                       "parallelism": ("single GPU" if world == 1 and not force_dist else
+                                       f"(encoder,video) units over {world} GPUs, RCCL {args.exchange} before fusion" if use_units else
+                                       f"data-parallel over videos on {world} GPUs, no data-path collective"),
                        "path_tflops": round(path_tflops, 1),
                        "path_frac_of_mfma_peak": round(path_tflops / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),
                        "flops_per_video_T": round(flops_video / 1e12, 3)},
