@@ -148,6 +148,7 @@ def main():
                          "ranks with an RCCL exchange of projected tokens before fusion (configs[2]'s encoder sharding)")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ln-fold", action="store_true", help="fold LN1 / LN2 into the qkv / fc1 GEMMs (exact algebra; opt-in)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; useful at --batch 1)")
     ap.add_argument("--mxfp8", action="store_true",
                     help="BASELINE.json configs[4] variant: block GEMMs on MXFP8 operands (NOT the headline bf16 metric; "
@@ -175,6 +176,9 @@ def main():
     from merv_amd import _lib
     lib = _lib.load()
     specs, path = build_path(device, concurrent=not args.sequential)
+    if args.ln_fold:
+        for enc in path.encoders:
+            enc.enable_ln_fold()
     if args.mxfp8:
         for enc in path.encoders:
             enc.enable_mxfp8()

@@ -183,6 +183,19 @@ int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M,
  *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
  */
 /*
+ * LayerNorm folded into the GEMM that consumes it (bf16 path, opt-in): for LN1 -> qkv and LN2 -> fc1 of every block
+ *   Linear(LayerNorm(x)) = rstd * (x . (W*gamma)^T) - rstd * mean * colsum(W*gamma) + (W . beta + bias)
+ * is exact algebra, so the encoder computes only the per-row statistics (one read of x instead of a read + write of the
+ * normalised copy) and the GEMM reads the residual stream directly; its epilogue applies the row scale and the rank-1
+ * correction in fp32. Rounding points differ from the reference's bf16(LayerNorm(x)): the weight product gamma*W is
+ * rounded to bf16 once more, the activations are not rounded at all. The library writes the folded weights into `buf`
+ * (merv_encoder_ln_fold_bytes(enc) bytes, 256-byte aligned, caller-owned). Ignored while MXFP8 mode is on. Call
+ * merv_encoder_workspace_bytes AFTER enabling.
+ */
+size_t merv_encoder_ln_fold_bytes(const merv_encoder *enc);
+int merv_encoder_enable_ln_fold(merv_encoder *enc, void *buf, size_t bytes, void *stream);
+
+/*
  * Encoder in MXFP8 mode: the GEMMs of every block (qkv, attention out-projection, fc1, fc2, and LanguageBind's temporal
  * qkv / out-projection) run on MXFP8 operands; LayerNorm statistics, attention, the patch embedding and the residual
  * stream stay bf16 / fp32. The library

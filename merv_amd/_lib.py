@@ -70,6 +70,8 @@ SIGNATURES = {
     "merv_fusion_backward_mix": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, C.POINTER(_vp), _vp]),
     "merv_projector_backward_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "merv_projector_backward": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _vp]),
+    "merv_encoder_ln_fold_bytes": (_sz, [_vp]),
+    "merv_encoder_enable_ln_fold": (C.c_int, [_vp, _vp, _sz, _vp]),
     "merv_encoder_mxfp8_bytes": (_sz, [_vp]),
     "merv_encoder_enable_mxfp8": (C.c_int, [_vp, _vp, _sz, _vp]),
     "merv_mxfp8_scale_bytes": (_sz, [_i32, _i32]),

@@ -41,12 +41,19 @@ struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + b
     const uint8_t *tqkv_q, *tqkv_s, *tproj_q, *tproj_s;  // LanguageBind temporal sub-block (null otherwise)
 };
 
+struct FoldLayer {  // LN1 folded into qkv, LN2 into fc1: bf16(W * gamma), sum_k of it, W.beta + bias
+    const bf16_t *qkv_w, *fc1_w;
+    const float *qkv_cs, *qkv_db, *fc1_cs, *fc1_db;
+};
+
 struct merv_encoder {
     merv_encoder_desc d;
     merv_encoder_weights w;
     std::vector<merv_layer_weights> layers;
     bool mx = false;            // MXFP8 mode enabled (merv_encoder_enable_mxfp8)
     std::vector<MxLayer> mxl;
+    bool fold = false;          // LayerNorm folded into the qkv / fc1 GEMMs (merv_encoder_enable_ln_fold)
+    std::vector<FoldLayer> fl;
     // derived geometry
     int hp;        // patches per side
     int P;         // patch tokens per sequence
@@ -117,6 +124,7 @@ struct Workspace {
     bf16_t *x, *y, *qkv, *h;
     uint8_t *aq, *asc;  // MXFP8 mode: quantised [M, dim] GEMM input (LayerNorm / attention output) and its block scales
     uint8_t *hq, *hsc;  // MXFP8 mode: quantised [M, mlp_dim] MLP hidden activations, written by fc1's epilogue
+    float* stats;       // folded LayerNorm: {rstd, -mean * rstd} per row
     size_t total;
 };
 Workspace carve(const merv_encoder* e, int batch, char* base) {
@@ -142,10 +150,47 @@ Workspace carve(const merv_encoder* e, int batch, char* base) {
         w.hq = (uint8_t*)take(M * e->d.mlp_dim);
         w.hsc = (uint8_t*)take(mx_scale_bytes((int)M, e->d.mlp_dim));
     }
+    w.stats = e->fold ? (float*)take(M * 2 * sizeof(float)) : nullptr;
     w.total = off;
     return w;
 }
 }  // namespace
+
+// ---- LayerNorm folded into the consuming GEMM (bf16 path) ----
+static size_t fold_weight_bytes(int N, int K) { return align_up((size_t)N * K * 2, 256) + 2 * align_up((size_t)N * 4, 256); }
+
+extern "C" size_t merv_encoder_ln_fold_bytes(const merv_encoder* e) {
+    if (!e) return 0;
+    return (size_t)e->d.layers * (fold_weight_bytes(3 * e->d.dim, e->d.dim) + fold_weight_bytes(e->d.mlp_dim, e->d.dim));
+}
+
+extern "C" int merv_encoder_enable_ln_fold(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
+    MERV_CHECK(e && buf, "merv_encoder_enable_ln_fold: null argument");
+    MERV_CHECK(bytes >= merv_encoder_ln_fold_bytes(e), "merv_encoder_enable_ln_fold: buffer too small");
+    MERV_CHECK(((uintptr_t)buf & 255) == 0, "merv_encoder_enable_ln_fold: buffer must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    const int D = e->d.dim, H = e->d.mlp_dim;
+    char* p = (char*)buf;
+    e->fl.assign(e->d.layers, FoldLayer{});
+    auto fold = [&](const void* w, const float* gamma, const float* beta, const float* bias, int N, int K, const bf16_t*& wf,
+                    const float*& cs, const float*& db) -> hipError_t {
+        bf16_t* wd = (bf16_t*)p;
+        float* csd = (float*)(p + align_up((size_t)N * K * 2, 256));
+        float* dbd = (float*)((char*)csd + align_up((size_t)N * 4, 256));
+        p += fold_weight_bytes(N, K);
+        wf = wd; cs = csd; db = dbd;
+        LnFoldArgs a{(const bf16_t*)w, gamma, beta, bias, wd, csd, dbd, N, K};
+        return launch_ln_fold(a, s);
+    };
+    for (int i = 0; i < e->d.layers; ++i) {
+        const merv_layer_weights& L = e->layers[i];
+        FoldLayer& f = e->fl[i];
+        MERV_HIP(fold(L.qkv_w, L.ln1_w, L.ln1_b, L.qkv_b, 3 * D, D, f.qkv_w, f.qkv_cs, f.qkv_db));
+        MERV_HIP(fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, H, D, f.fc1_w, f.fc1_cs, f.fc1_db));
+    }
+    e->fold = true;
+    return 0;
+}
 
 // ---- MXFP8 mode of the encoder blocks (BASELINE.json configs[4]) ----
 static size_t mx_weight_bytes(int N, int K) { return align_up((size_t)N * K, 256) + align_up(mx_scale_bytes(N, K), 256); }
@@ -274,10 +319,18 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
             else MERV_HIP(launch_gemm(o, s));
         }
         {
-            LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
-            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
-            MERV_HIP(launch_layernorm(ln, s));
+            const bool folded = e->fold && !e->mx;  // statistics only; the normalisation is algebra in the GEMM epilogue
             GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
+            if (folded) {
+                RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
+                MERV_HIP(launch_row_stats(rs, s));
+                q.A = ws.x; q.W = e->fl[li].qkv_w; q.bias = e->fl[li].qkv_db;
+                q.row_stats = ws.stats; q.ln_colsum = e->fl[li].qkv_cs;
+            } else {
+                LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
+                if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+                MERV_HIP(launch_layernorm(ln, s));
+            }
             if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
             else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
@@ -289,10 +342,18 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
             else MERV_HIP(launch_gemm(o, s));
         }
         {
-            LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
-            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
-            MERV_HIP(launch_layernorm(ln, s));
+            const bool folded = e->fold && !e->mx;
             GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
+            if (folded) {
+                RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
+                MERV_HIP(launch_row_stats(rs, s));
+                f1.A = ws.x; f1.W = e->fl[li].fc1_w; f1.bias = e->fl[li].fc1_db;
+                f1.row_stats = ws.stats; f1.ln_colsum = e->fl[li].fc1_cs;
+            } else {
+                LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
+                if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+                MERV_HIP(launch_layernorm(ln, s));
+            }
             if (e->mx) {
                 f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups;
                 MERV_HIP(mx_gemm(f1, ws.aq, ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));

@@ -113,11 +113,29 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
         if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
+        // folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]; the row of acc[i][j] is j * 16 + frow of this part
+        float2 rs[MI];
+        if (p.row_stats) {
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                const f32x4 v = acc[i][part * MI + j];
+                int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
+                m = m < p.M ? m : p.M - 1;
+                rs[j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 cs = float4{0.f, 0.f, 0.f, 0.f};
+            if (p.row_stats) cs = *(const float4*)(p.ln_colsum + wn0 + i * 16 + fq * 4);  // loaded here: keeps it out of the K-loop's registers
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                f32x4 v = acc[i][part * MI + j];
+                if (p.row_stats) {
+                    v[0] = fmaf(v[0], rs[j].x, rs[j].y * cs.x);
+                    v[1] = fmaf(v[1], rs[j].x, rs[j].y * cs.y);
+                    v[2] = fmaf(v[2], rs[j].x, rs[j].y * cs.z);
+                    v[3] = fmaf(v[3], rs[j].x, rs[j].y * cs.w);
+                }
                 const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
                 const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
                 u32x2 o;
@@ -127,6 +145,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 const int chunk = (2 * i + (fq >> 1)) ^ (row & 7);
                 *(u32x2*)(stg + row * 128 + chunk * 16 + 8 * (fq & 1)) = o;
             }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {

@@ -23,6 +23,11 @@ struct GemmArgs {
     const void* mx_scale_a;  // E8M0 block scales of A, layout of mx_quantize (below)
     const void* mx_scale_w;
     int mx_groups_a, mx_groups_w;  // 64-row groups in each scale array (ceil(rows / 64))
+    // LayerNorm folded into the GEMM (A = the raw residual stream, W = bf16(W * gamma)): the epilogue's value becomes
+    // acc * row_stats[m].x + row_stats[m].y * ln_colsum[n] + bias[n], with row_stats = {rstd, -mean * rstd} and
+    // ln_colsum[n] = sum_k W'[n][k]; bias then holds W.beta + the layer's bias (all prepared once by launch_ln_fold)
+    const float* row_stats;   // [M][2] or nullptr
+    const float* ln_colsum;   // [N]
     // any launch: when mx_out_q is set the epilogue writes its (bf16-rounded) result as MXFP8 -- e4m3 [M, N] + block
     // scales in the layout of mx_quantize -- instead of bf16 C (the next GEMM's quantised input, e.g. fc1 -> fc2)
     uint8_t* mx_out_q;
@@ -66,6 +71,29 @@ struct LayerNormArgs {
     int mx_groups;        // ceil(M / 64)
 };
 hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s);
+
+// Per-row LayerNorm statistics only (for the folded form): stats[m] = {rstd, -mean * rstd}.
+struct RowStatsArgs {
+    const bf16_t* x;  // [M, D]
+    float* stats;     // [M][2]
+    int M, D;
+    float eps;
+};
+hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s);
+
+// One-time fold of a LayerNorm into the Linear that consumes it: wf[n][k] = bf16(w[n][k] * gamma[k]),
+// colsum[n] = sum_k wf[n][k] (of the ROUNDED values, so the algebra stays exact), dbias[n] = sum_k w[n][k] * beta[k] + bias[n].
+struct LnFoldArgs {
+    const bf16_t* w;      // [N, K]
+    const float* gamma;   // [K]
+    const float* beta;    // [K]
+    const float* bias;    // [N] or nullptr
+    bf16_t* wf;           // [N, K]
+    float* colsum;        // [N]
+    float* dbias;         // [N]
+    int N, K;
+};
+hipError_t launch_ln_fold(const LnFoldArgs& a, hipStream_t s);
 
 // Multi-head self attention over packed QKV rows: qkv[row][{q,k,v} * D + head * 64 + d], head_dim = 64.
 // Sequence s covers rows [s*L, (s+1)*L). out[row][head*64 + d].

@@ -91,6 +91,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LayerNorm folded into its consumer GEMM: this kernel only produces the per-row statistics (one read of x, 8 bytes
+// written per row); the normalisation itself is algebra in the GEMM epilogue (kernels.h, GemmArgs::row_stats).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(RowStatsArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nchunk = p.D >> 3;
+    float v[LN_MAX_CHUNKS][8];
+    const bf16_t* xr = p.x + (size_t)row * p.D;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+            unpack8(*(const u32x4*)(xr + c * 8), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_CHUNKS; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    if (lane == 0) *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
+}
+
+// one block per output row n
+__global__ __launch_bounds__(256) void ln_fold_kernel(LnFoldArgs p) {
+    const int n = blockIdx.x;
+    const bf16_t* wr = p.w + (size_t)n * p.K;
+    bf16_t* wo = p.wf + (size_t)n * p.K;
+    float cs = 0.f, db = 0.f;
+    for (int k = threadIdx.x; k < p.K; k += 256) {
+        const float w = bf2f(wr[k]);
+        const bf16_t r = f2bf(w * p.gamma[k]);
+        wo[k] = r;
+        cs += bf2f(r);
+        db += w * p.beta[k];
+    }
+    __shared__ float red[2][4];
+    cs = wave_sum(cs);
+    db = wave_sum(db);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = cs; red[1][threadIdx.x >> 6] = db; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p.colsum[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        p.dbias[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3] + (p.bias ? p.bias[n] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // im2col: one thread per 8 output elements (16 B store). Replaces the unfold inside Conv2d / Conv3d patch
 // embedding (timm PatchEmbed, HF CLIPVisionEmbeddings, HF VivitTubeletEmbeddings).
 // ---------------------------------------------------------------------------------------------------------
@@ -306,6 +365,19 @@ hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
     const long long total = (long long)a.nseq * a.npre * (a.D / 8);
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(prefix_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.D % 8 != 0 || a.D > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_fold(const LnFoldArgs& a, hipStream_t s) {
+    if (a.N <= 0 || a.K <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(a.N), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

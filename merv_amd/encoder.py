@@ -169,6 +169,17 @@ class HipEncoder:
             self._lib.merv_encoder_destroy(h)
             self._handle = None
 
+    def enable_ln_fold(self) -> "HipEncoder":
+        """Fold LN1 into qkv and LN2 into fc1 (exact algebra, include/merv_hip.h): the encoder then computes row statistics
+        only and the GEMMs read the residual stream directly."""
+        need = self._lib.merv_encoder_ln_fold_bytes(self._handle)
+        self._fold_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        check(self._lib.merv_encoder_enable_ln_fold(self._handle, ptr(self._fold_buf), need,
+                                                    torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_ln_fold")
+        self._ws = None
+        self.ln_fold = True
+        return self
+
     def enable_mxfp8(self) -> "HipEncoder":
         """Switch the four block GEMMs to MXFP8 operands (BASELINE.json configs[4]; include/merv_hip.h). The library
         quantises the weights into a buffer this object keeps alive. Not the default: trades the bf16 tolerance for speed."""

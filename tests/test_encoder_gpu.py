@@ -79,3 +79,32 @@ def test_projector_vs_oracle(dev):
         out = proj(tok.to(dev).reshape(B, T, S * S, C))
         assert out.shape == (B, 1024, llm)
         assert rel_l2(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["languagebind", "dinov2", "vivit", "siglip"])
+def test_ln_fold_matches_oracle_and_plain_path(dev, name):
+    """LayerNorm folded into qkv / fc1 (exact algebra, different rounding points): same tolerance against the oracle as
+    the plain path, and the two HIP paths agree with each other to bf16 noise. LayerNorm weights are drawn away from
+    (1, 0) and the input is given a per-row offset so that gamma, beta and the mean term all matter."""
+    import dataclasses
+    from oracle import merv_oracle as O
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    spec = next(s for s in merv_full_specs() if s.name == name)
+    spec = dataclasses.replace(spec, layers=2, frames=8 if name in ("languagebind", "vivit") else 4)
+    W = random_weights(spec, seed=21)
+    g = torch.Generator().manual_seed(4)
+    for L in W["layers"]:
+        for k in ("ln1_w", "ln2_w"):
+            L[k] = 1.0 + 0.5 * torch.randn(spec.dim, generator=g)
+        for k in ("ln1_b", "ln2_b"):
+            L[k] = 0.5 * torch.randn(spec.dim, generator=g)
+    W["pos"] = W["pos"] + 0.7  # non-zero row means in the residual stream
+    pix = torch.randn(spec.pixel_shape(1), generator=g)
+    cfg = O.EncoderCfg(**{k: getattr(spec, k) for k in O.EncoderCfg.__dataclass_fields__})
+    ref = O.encoder_forward(pix, cfg, W)
+    plain = HipEncoder(spec, W, dev).forward(pix.to(dev)).float().cpu()
+    folded = HipEncoder(spec, W, dev).enable_ln_fold().forward(pix.to(dev)).float().cpu()
+    assert rel_l2(plain, ref) < 2e-2
+    assert rel_l2(folded, ref) < 2e-2
+    assert rel_l2(folded, plain) < 1.5e-2
