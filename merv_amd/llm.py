@@ -89,15 +89,34 @@ class LlamaBackbone:
     @torch.inference_mode()
     def generate_from_embeds(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 32, do_sample: bool = False,
                              temperature: float = 1.0, eos_token_id: Optional[int] = None,
-                             generator: Optional[torch.Generator] = None) -> torch.LongTensor:
+                             generator: Optional[torch.Generator] = None, use_graph: bool = True) -> torch.LongTensor:
         """Prefill on `inputs_embeds` [B, S, D] (merv.py:723-734), then decode token by token on the KV cache
         (merv.py:524-538). Returns the new token ids [B, <= max_new_tokens]."""
-        out = self.llm(inputs_embeds=inputs_embeds.to(self.dtype), use_cache=True)
-        past = out.past_key_values
-        logits = out.logits[:, -1].float()
+        if use_graph and inputs_embeds.is_cuda and inputs_embeds.shape[1] + max_new_tokens + 1 <= self.config.max_position_embeddings:
+            # static-cache prefill + hipGraph-replayed decode steps (StaticDecoder above)
+            need = inputs_embeds.shape[1] + max_new_tokens + 1
+            bucket = min((need + 255) // 256 * 256, self.config.max_position_embeddings)  # cache length, reused across calls
+            key = (bucket, inputs_embeds.shape[0])
+            if not hasattr(self, "_decoders"):
+                self._decoders = {}
+            if key not in self._decoders:
+                self._decoders.clear()  # one static cache at a time (a 7B model's is ~0.5 GB per 1024 positions)
+                self._decoders[key] = StaticDecoder(self.llm, bucket, inputs_embeds.shape[0])
+            dec = self._decoders[key]
+            logits = dec.prefill(inputs_embeds)
+            step = lambda tok: dec.decode(tok, use_graph=True)
+        else:
+            out = self.llm(inputs_embeds=inputs_embeds.to(self.dtype), use_cache=True)
+            state = {"past": out.past_key_values}
+            logits = out.logits[:, -1].float()
+
+            def step(tok):
+                o = self.llm(input_ids=tok[:, None], past_key_values=state["past"], use_cache=True)
+                state["past"] = o.past_key_values
+                return o.logits[:, -1].float()
         new_tokens = []
         done = torch.zeros(inputs_embeds.shape[0], dtype=torch.bool, device=inputs_embeds.device)
-        for _ in range(max_new_tokens):
+        for i in range(max_new_tokens):
             if do_sample:
                 probs = torch.softmax(logits / max(temperature, 1e-6), dim=-1)
                 nxt = torch.multinomial(probs, 1, generator=generator)[:, 0]
@@ -106,12 +125,131 @@ class LlamaBackbone:
             new_tokens.append(nxt)
             if eos_token_id is not None:
                 done |= nxt == eos_token_id
-                if bool(done.all()):
+                if (i % 8 == 7 or i == max_new_tokens - 1) and bool(done.all()):  # one host sync per 8 tokens
                     break
-            out = self.llm(input_ids=nxt[:, None], past_key_values=past, use_cache=True)
-            past = out.past_key_values
-            logits = out.logits[:, -1].float()
-        return torch.stack(new_tokens, 1)
+            if i + 1 < max_new_tokens:
+                logits = step(nxt)
+        ids = torch.stack(new_tokens, 1)
+        if eos_token_id is not None:  # the EOS test above runs every 8 tokens: cut at the step where every row had finished
+            all_done = ((ids == eos_token_id).cumsum(1) > 0).all(0)
+            if bool(all_done.any()):
+                ids = ids[:, : int(all_done.float().argmax()) + 1]
+        return ids
+
+
+class StaticDecoder:
+    """Prefill + token-by-token decode of a Llama / Mistral `*ForCausalLM` written with plain torch ops on a static KV
+    cache, so that ONE decode step has fixed shapes and replays from a hipGraph (torch.cuda.CUDAGraph). HF's eager decode
+    is launch-bound at batch 1 (≈350 small kernels per token); the graph removes the per-launch overhead. Still
+    PyTorch-ROCm (library GEMMs, `F.scaled_dot_product_attention`): plumbing around the hand-off, not part of the HIP
+    path. Uses the HF module's own parameters (no copies); rotary convention, RMSNorm and GQA as in
+    transformers' modeling_llama / modeling_mistral (checked against the module's own forward in tests)."""
+
+    def __init__(self, hf_model, max_len: int, batch: int = 1) -> None:
+        import torch.nn.functional as F
+        self.F = F
+        self.m = hf_model
+        cfg = hf_model.config
+        self.cfg = cfg
+        self.H, self.Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        self.eps = cfg.rms_norm_eps
+        self.max_len, self.B = max_len, batch
+        p = next(hf_model.parameters())
+        self.dev, self.dt = p.device, p.dtype
+        theta = getattr(cfg, "rope_theta", None)
+        if theta is None and isinstance(getattr(cfg, "rope_parameters", None), dict):
+            theta = cfg.rope_parameters.get("rope_theta")
+        theta = float(theta or 10000.0)
+        inv = 1.0 / (theta ** (torch.arange(0, self.hd, 2, dtype=torch.float32, device=self.dev) / self.hd))
+        fr = torch.outer(torch.arange(max_len, dtype=torch.float32, device=self.dev), inv)
+        emb = torch.cat([fr, fr], dim=-1)
+        self.cos, self.sin = emb.cos().to(self.dt), emb.sin().to(self.dt)  # [max_len, hd]
+        L = cfg.num_hidden_layers
+        self.K = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
+        self.V = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
+        self.ar = torch.arange(max_len, device=self.dev)
+        self.graph = None
+
+    def _rms(self, x, w):
+        xf = x.float()
+        return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)).to(x.dtype)
+
+    @staticmethod
+    def _rot(x):
+        h = x.shape[-1] // 2
+        return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+    def _layer(self, li, x, cos, sin, pos_idx, mask, S):
+        F = self.F
+        lyr = self.m.model.layers[li]
+        a = lyr.self_attn
+        B = x.shape[0]
+        h = self._rms(x, lyr.input_layernorm.weight)
+        q = F.linear(h, a.q_proj.weight, a.q_proj.bias).view(B, S, self.H, self.hd).transpose(1, 2)
+        k = F.linear(h, a.k_proj.weight, a.k_proj.bias).view(B, S, self.Hkv, self.hd).transpose(1, 2)
+        v = F.linear(h, a.v_proj.weight, a.v_proj.bias).view(B, S, self.Hkv, self.hd).transpose(1, 2)
+        q = q * cos + self._rot(q) * sin
+        k = k * cos + self._rot(k) * sin
+        self.K[li].index_copy_(2, pos_idx, k)
+        self.V[li].index_copy_(2, pos_idx, v)
+        if mask is None:  # prefill: causal over the S new positions only (the cache beyond them is not read)
+            o = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=self.H != self.Hkv)
+        else:  # decode: one query against the whole static cache, slots > position masked off
+            o = F.scaled_dot_product_attention(q, self.K[li], self.V[li], attn_mask=mask, enable_gqa=self.H != self.Hkv)
+        x = x + F.linear(o.transpose(1, 2).reshape(B, S, self.H * self.hd), a.o_proj.weight, a.o_proj.bias)
+        h = self._rms(x, lyr.post_attention_layernorm.weight)
+        mlp = lyr.mlp
+        return x + F.linear(F.silu(F.linear(h, mlp.gate_proj.weight)) * F.linear(h, mlp.up_proj.weight), mlp.down_proj.weight)
+
+    @torch.inference_mode()
+    def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        """inputs_embeds [B, S, D] -> logits of the last position [B, vocab] (fp32); fills cache slots 0..S-1."""
+        B, S, _ = inputs_embeds.shape
+        assert B == self.B and S < self.max_len
+        x = inputs_embeds.to(self.dt)
+        pos = self.ar[:S]
+        cos, sin = self.cos[:S][None, None], self.sin[:S][None, None]
+        for li in range(self.cfg.num_hidden_layers):
+            x = self._layer(li, x, cos, sin, pos, None, S)
+        if not hasattr(self, "pos"):
+            self.pos = torch.tensor([S], device=self.dev)
+        else:
+            self.pos.fill_(S)  # same tensor: a captured decode graph keeps reading it
+        return self.F.linear(self._rms(x[:, -1:], self.m.model.norm.weight), self.m.lm_head.weight)[:, 0].float()
+
+    def _step(self):
+        x = self.m.model.embed_tokens(self.tok)
+        cos = self.cos.index_select(0, self.pos)[None, None]
+        sin = self.sin.index_select(0, self.pos)[None, None]
+        mask = (self.ar <= self.pos)[None, None, None, :]
+        for li in range(self.cfg.num_hidden_layers):
+            x = self._layer(li, x, cos, sin, self.pos, mask, 1)
+        return self.F.linear(self._rms(x, self.m.model.norm.weight), self.m.lm_head.weight)[:, 0].float()
+
+    @torch.inference_mode()
+    def decode(self, token: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
+        """token [B] (the token at position self.pos) -> logits for the next position [B, vocab] (fp32)."""
+        if self.graph is None:
+            self.tok = token[:, None].clone()
+            if not use_graph:
+                out = self._step()
+                self.pos += 1
+                return out
+            self._step()  # warm-up outside the capture (same slot is rewritten identically by the replay)
+            torch.cuda.synchronize(self.dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logits = self._step()
+        else:
+            self.tok.copy_(token[:, None])
+        if use_graph:
+            self.graph.replay()
+            self.pos += 1
+            return self.logits
+        out = self._step()
+        self.pos += 1
+        return out
 
 
 # === Language Model Registry (materialize.py:76-101, llama2.py:24-51): ids wired on this path -> (family, geometry) ===

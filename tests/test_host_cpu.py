@@ -281,3 +281,27 @@ def test_oracle_training_batch_assembly_layout():
     labels[:, :3] = -100
     want = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, 11), labels[:, 1:].reshape(-1), ignore_index=-100)
     assert torch.allclose(O.causal_lm_loss(logits, labels), want)
+
+
+def test_static_decoder_matches_hf_forward_cpu():
+    """StaticDecoder (torch-native prefill + static-cache decode, the body of the hipGraph-replayed decode step) against
+    the HF module's own forward with its dynamic cache, fp32, Llama (MHA) and Mistral (GQA)."""
+    from merv_amd.llm import LlamaBackbone, StaticDecoder
+    for fam, kv in (("llama", 4), ("mistral", 2)):
+        cfg = dict(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                   num_key_value_heads=kv, max_position_embeddings=64, rms_norm_eps=1e-5, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+        if fam == "mistral":
+            cfg["sliding_window"] = None
+        bb = LlamaBackbone(cfg, device="cpu", dtype=torch.float32, family=fam)
+        emb = torch.randn(2, 9, 64, generator=torch.Generator().manual_seed(1))
+        dec = StaticDecoder(bb.llm, 16, 2)
+        with torch.inference_mode():
+            out = bb.llm(inputs_embeds=emb, use_cache=True)
+            assert (dec.prefill(emb) - out.logits[:, -1]).abs().max() < 1e-5
+            for _ in range(3):
+                tok = out.logits[:, -1].argmax(-1)
+                out = bb.llm(input_ids=tok[:, None], past_key_values=out.past_key_values, use_cache=True)
+                assert (dec.decode(tok, use_graph=False) - out.logits[:, -1]).abs().max() < 1e-5
+        # and generate_from_embeds cuts at the step where every row has produced EOS
+        ids = bb.generate_from_embeds(emb, max_new_tokens=12, eos_token_id=int(out.logits[0, -1].argmax()), use_graph=False)
+        assert 1 <= ids.shape[1] <= 12
