@@ -205,6 +205,9 @@ int merv_encoder_enable_ln_fold(merv_encoder *enc, void *buf, size_t bytes, void
  */
 size_t merv_encoder_mxfp8_bytes(const merv_encoder *enc);
 int merv_encoder_enable_mxfp8(merv_encoder *enc, void *buf, size_t bytes, void *stream);
+/* Which block GEMMs run on MXFP8 once the mode is enabled: bit 0 qkv (and the temporal qkv), bit 1 attention
+ * out-projection (and the temporal one), bit 2 fc1, bit 3 fc2; default 15. The others stay bf16 (accuracy / speed dial). */
+int merv_encoder_set_mxfp8_mask(merv_encoder *enc, int32_t mask);
 size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K);
 int merv_quantize_mxfp8(const void *x, int32_t rows, int32_t K, int32_t ld, void *q, void *scales, void *stream);
 int merv_gemm_mxfp8(const void *A8, const void *scale_a, const void *W8, const void *scale_w, void *C, const float *bias,
@@ -250,6 +253,9 @@ int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, in
  * 4: 256x128 with staggered half-blocks, 6: 128x128 four-deep ring, 7: 256x256 eight-phase where the shape allows it;
  * second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
+/* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */
+int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t M, int32_t N, int32_t K, void *q_out,
+                           void *scales_out, void *stream);
 
 /*
  * Per-launch HIP-event timing (bench.py roofline leg). class bits: 0 GEMM, 1 attention, 2 temporal attention,

@@ -51,6 +51,7 @@ struct merv_encoder {
     merv_encoder_weights w;
     std::vector<merv_layer_weights> layers;
     bool mx = false;            // MXFP8 mode enabled (merv_encoder_enable_mxfp8)
+    int mx_mask = 15;           // which block GEMMs use it: bit 0 qkv (+ temporal qkv), 1 out-projection (+ temporal), 2 fc1, 3 fc2
     std::vector<MxLayer> mxl;
     bool fold = false;          // LayerNorm folded into the qkv / fc1 GEMMs (merv_encoder_enable_ln_fold)
     std::vector<FoldLayer> fl;
@@ -155,6 +156,13 @@ Workspace carve(const merv_encoder* e, int batch, char* base) {
     return w;
 }
 }  // namespace
+
+extern "C" int merv_encoder_set_mxfp8_mask(merv_encoder* e, int32_t mask) {
+    MERV_CHECK(e, "merv_encoder_set_mxfp8_mask: null encoder");
+    MERV_CHECK(mask >= 0 && mask <= 15, "merv_encoder_set_mxfp8_mask: mask is 4 bits (qkv, out-projection, fc1, fc2)");
+    e->mx_mask = mask;
+    return 0;
+}
 
 // ---- LayerNorm folded into the consuming GEMM (bf16 path) ----
 static size_t fold_weight_bytes(int N, int K) { return align_up((size_t)N * K * 2, 256) + 2 * align_up((size_t)N * 4, 256); }
@@ -292,6 +300,8 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
     // MXFP8 mode. Every GEMM input arrives quantised from its producer: the LayerNorms, the attention kernels and fc1's
     // epilogue write e4m3 + block scales directly (no separate quantisation pass, no bf16 copy of those tensors).
     const int mx_groups = (M + 63) / 64;
+    const bool mx_qkv = e->mx && (e->mx_mask & 1), mx_proj = e->mx && (e->mx_mask & 2), mx_fc1 = e->mx && (e->mx_mask & 4),
+               mx_fc2 = e->mx && (e->mx_mask & 8);
     auto mx_gemm = [&](GemmArgs g, const uint8_t* aq, const uint8_t* asc, const uint8_t* wq, const uint8_t* wsc) -> hipError_t {
         g.A = (const bf16_t*)aq; g.lda = g.K;
         g.W = (const bf16_t*)wq; g.ldw = g.K;
@@ -305,21 +315,21 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         if (d.temporal_frames > 0) {
             // x += temporal_embedding[t]; x += out_proj(temporal_attn(LN_t(x)))   (modeling_video.py:133-155)
             LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
-            if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+            if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
             MERV_HIP(launch_layernorm(ln, s));
             GemmArgs q = gemm_args(ws.y, D, L.t_qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.t_qkv_b, ACT_NONE);
-            if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
+            if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
             else MERV_HIP(launch_gemm(q, s));
             TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
-            if (e->mx) { ta.mx_q = ws.aq; ta.mx_scales = ws.asc; ta.mx_groups = mx_groups; }
+            if (mx_proj) { ta.mx_q = ws.aq; ta.mx_scales = ws.asc; ta.mx_groups = mx_groups; }
             MERV_HIP(launch_temporal_attention(ta, s));
             GemmArgs o = gemm_args(ws.y, D, L.t_proj_w, D, ws.x, D, M, D, L.t_proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D;
-            if (e->mx) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
+            if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
             else MERV_HIP(launch_gemm(o, s));
         }
         {
-            const bool folded = e->fold && !e->mx;  // statistics only; the normalisation is algebra in the GEMM epilogue
+            const bool folded = e->fold && !mx_qkv;  // statistics only; the normalisation is algebra in the GEMM epilogue
             GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
             if (folded) {
                 RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
@@ -328,21 +338,21 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
                 q.row_stats = ws.stats; q.ln_colsum = e->fl[li].qkv_cs;
             } else {
                 LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
-                if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+                if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
                 MERV_HIP(launch_layernorm(ln, s));
             }
-            if (e->mx) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
+            if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
             else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
-            if (e->mx) { at.mx_q = ws.aq; at.mx_scales = ws.asc; at.mx_groups = mx_groups; }
+            if (mx_proj) { at.mx_q = ws.aq; at.mx_scales = ws.asc; at.mx_groups = mx_groups; }
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
-            if (e->mx) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
+            if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
             else MERV_HIP(launch_gemm(o, s));
         }
         {
-            const bool folded = e->fold && !e->mx;
+            const bool folded = e->fold && !mx_fc1;
             GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
             if (folded) {
                 RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
@@ -351,18 +361,15 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
                 f1.row_stats = ws.stats; f1.ln_colsum = e->fl[li].fc1_cs;
             } else {
                 LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
-                if (e->mx) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+                if (mx_fc1) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
                 MERV_HIP(launch_layernorm(ln, s));
             }
-            if (e->mx) {
-                f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups;
-                MERV_HIP(mx_gemm(f1, ws.aq, ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
-            } else {
-                MERV_HIP(launch_gemm(f1, s));
-            }
+            if (mx_fc2) { f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups; }  // fc2's input, whichever kernel runs fc1
+            if (mx_fc1) MERV_HIP(mx_gemm(f1, ws.aq, ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
+            else MERV_HIP(launch_gemm(f1, s));
             GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
-            if (e->mx) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
+            if (mx_fc2) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
             else MERV_HIP(launch_gemm(f2, s));
         }
     }
@@ -540,6 +547,17 @@ extern "C" int merv_gemm_mxfp8(const void* A8, const void* scale_a, const void* 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldres = ldres; g.act = act;
     g.mx_scale_a = scale_a; g.mx_scale_w = scale_w; g.mx_groups_a = (M + 63) / 64; g.mx_groups_w = N / 64;
     MERV_HIP(launch_gemm_mx(g, (hipStream_t)stream_));
+    return 0;
+}
+
+// test hook: bf16 GEMM (automatic tile choice, incl. the split plan) whose epilogue writes MXFP8 instead of bf16
+extern "C" int merv_debug_gemm_mx_out(const void* A, const void* W, void* C_unused, int32_t M, int32_t N, int32_t K, void* q_out,
+                                      void* scales_out, void* stream_) {
+    MERV_CHECK(A && W && q_out && scales_out, "merv_debug_gemm_mx_out: null argument");
+    MERV_CHECK(N % 128 == 0 && K % 64 == 0, "merv_debug_gemm_mx_out: bad geometry");
+    GemmArgs g = gemm_args((const bf16_t*)A, K, W, K, (bf16_t*)C_unused, N, M, N, nullptr, ACT_NONE);
+    g.mx_out_q = (uint8_t*)q_out; g.mx_out_scales = (uint8_t*)scales_out; g.mx_out_groups = (M + 63) / 64;
+    MERV_HIP(launch_gemm(g, (hipStream_t)stream_));
     return 0;
 }
 

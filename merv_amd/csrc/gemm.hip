@@ -789,6 +789,11 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     rest.A = a.A + (size_t)rows1 * a.lda;
     rest.C = a.C + (size_t)rows1 * a.ldc;
     if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
+    if (a.row_stats) rest.row_stats = a.row_stats + 2 * (size_t)rows1;
+    if (a.mx_out_q) {  // rows1 is a multiple of 256: whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
+        rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;
+        rest.mx_out_scales = a.mx_out_scales + (size_t)(rows1 / 64) * 256;
+    }
     return dispatch(rest, false);
 }
 

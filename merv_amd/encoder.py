@@ -180,13 +180,18 @@ class HipEncoder:
         self.ln_fold = True
         return self
 
-    def enable_mxfp8(self) -> "HipEncoder":
-        """Switch the four block GEMMs to MXFP8 operands (BASELINE.json configs[4]; include/merv_hip.h). The library
-        quantises the weights into a buffer this object keeps alive. Not the default: trades the bf16 tolerance for speed."""
+    MX_GEMMS = {"qkv": 1, "proj": 2, "fc1": 4, "fc2": 8}
+
+    def enable_mxfp8(self, gemms=("qkv", "proj", "fc1", "fc2")) -> "HipEncoder":
+        """Switch block GEMMs to MXFP8 operands (BASELINE.json configs[4]; include/merv_hip.h). `gemms` selects which of
+        qkv / proj / fc1 / fc2 (the rest stay bf16). The library quantises the weights into a buffer this object keeps
+        alive. Not the default: trades the bf16 tolerance for speed."""
         need = self._lib.merv_encoder_mxfp8_bytes(self._handle)
         self._mx_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
         check(self._lib.merv_encoder_enable_mxfp8(self._handle, ptr(self._mx_buf), need,
                                                   torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_mxfp8")
+        mask = sum(self.MX_GEMMS[g] for g in set(gemms))
+        check(self._lib.merv_encoder_set_mxfp8_mask(self._handle, mask), "merv_encoder_set_mxfp8_mask")
         self._ws = None  # the workspace grows
         self.mxfp8 = True
         return self

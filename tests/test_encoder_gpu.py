@@ -108,3 +108,21 @@ def test_ln_fold_matches_oracle_and_plain_path(dev, name):
     assert rel_l2(plain, ref) < 2e-2
     assert rel_l2(folded, ref) < 2e-2
     assert rel_l2(folded, plain) < 1.5e-2
+
+
+def test_ln_fold_at_split_gemm_sizes(dev):
+    """B=8 LanguageBind rows (32896 = 128.5 m-tiles): the qkv / fc1 GEMMs take the round-filling split, so the remaining
+    rows' launch must read ITS rows of the LayerNorm statistics. Folded vs plain HIP path, one block, every output row."""
+    import dataclasses
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    spec = dataclasses.replace(next(s for s in merv_full_specs() if s.name == "languagebind"), layers=1)
+    W = random_weights(spec, seed=5)
+    g = torch.Generator().manual_seed(6)
+    W["layers"][0]["ln1_w"] = 1.0 + 0.5 * torch.randn(spec.dim, generator=g)
+    W["layers"][0]["ln2_b"] = 0.5 * torch.randn(spec.dim, generator=g)
+    pix = torch.randn(spec.pixel_shape(8), generator=g).to(torch.bfloat16).to(dev)
+    plain = HipEncoder(spec, W, dev).forward(pix).float()
+    folded = HipEncoder(spec, W, dev).enable_ln_fold().forward(pix).float()
+    per_video = ((folded - plain).flatten(1).norm(dim=1) / plain.flatten(1).norm(dim=1)).cpu()
+    assert float(per_video.max()) < 1.5e-2, per_video  # the last video's rows are the ones behind the split

@@ -32,3 +32,25 @@ def test_variant(dev, variant, M, N, K):
         lib.merv_debug_set_gemm_variant(0)
     assert rel_l2(x, ref) < 6e-3, (variant, M, N, K)
     assert rel_l2(plain, a.float() @ w.float().t()) < 6e-3
+
+
+def test_split_launch_carries_row_offsets_of_optional_epilogue_inputs(dev):
+    """A GEMM large enough for the round-filling split (eight-phase part + remaining rows): the folded-LayerNorm row
+    statistics and the MXFP8 output of the SECOND launch must be offset by the rows the first one took."""
+    import ctypes as C
+    from merv_amd import _lib, ops
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    M, N, K = 66000, 512, 256  # 257 full m-tiles x 2 n-tiles: 2 complete rounds to the eight-phase kernel, 464 rows left
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    plain = ops.gemm(a, w)
+    q, sc = ops.quantize_mxfp8(plain)
+    # MXFP8 output straight from the epilogue == quantising the bf16 result afterwards, incl. the remainder rows
+    q2 = torch.empty(M, N, dtype=torch.uint8, device=dev)
+    sc2 = torch.zeros_like(sc)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    check(lib.merv_debug_gemm_mx_out(ptr(a), ptr(w), ptr(out), M, N, K, ptr(q2), ptr(sc2), torch.cuda.current_stream(dev).cuda_stream),
+          "merv_debug_gemm_mx_out")
+    assert torch.equal(q2, q) and torch.equal(ops.mxfp8_scales_to_rows(sc2, M, N), ops.mxfp8_scales_to_rows(sc, M, N))
