@@ -173,8 +173,8 @@ int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M,
 /* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
 /*
  * ---- MXFP8 mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs") ----
- * OCP Microscaling FP8: e4m3 elements, one E8M0 scale per 32 consecutive k (shared exponent floor(log2 amax) - 8,
- * round-to-nearest-even, saturation at +-448), consumed by v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA
+ * OCP Microscaling FP8: e4m3 elements, one E8M0 scale per 32 consecutive k (shared exponent floor(log2 amax) - 8, plus
+ * one when the scaled block maximum would exceed 448 so that nothing saturates; round-to-nearest-even), consumed by v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA
  * rate. There is no counterpart in the reference (it runs bf16 autocast, merv.py:816): this mode trades the bf16
  * tolerance for throughput and is never the default.
  * merv_quantize_mxfp8: x bf16 [rows, K] (ld elements) -> q [rows, K] bytes + scales (merv_mxfp8_scale_bytes(rows, K)

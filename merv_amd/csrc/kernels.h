@@ -37,8 +37,8 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s);
 
-// bf16 [rows, K] -> MXFP8: q [rows, K] OCP e4m3 bytes + one E8M0 scale per 32 consecutive k (OCP MX: shared exponent
-// floor(log2(amax)) - 8, elements rounded to nearest even and saturated to +-448). Scale layout, chosen so that the
+// bf16 [rows, K] -> MXFP8: q [rows, K] OCP e4m3 bytes + one E8M0 scale per 32 consecutive k (shared exponent
+// floor(log2(amax)) - 8, +1 when the scaled maximum would exceed 448; elements rounded to nearest even). Scale layout, chosen so that the
 // GEMM's lane (row % 16, kblock % 4) reads the scales of four row fragments as one dword:
 //   scales[kblock / 4][row / 64][(kblock % 4) * 16 + row % 16][(row % 64) / 16]      (bytes; rows padded to 64)
 struct MxQuantArgs {

@@ -1,6 +1,6 @@
 // MXFP8 quantisation for the fp8 encoder-GEMM mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs"). OCP
-// Microscaling: blocks of 32 consecutive k share one E8M0 scale 2^e, e = floor(log2(max|v|)) - 8 (8 = emax of e4m3);
-// elements are v / 2^e rounded to nearest even into OCP e4m3 and saturated to +-448. HBM-bound: reads 64 B, writes
+// Microscaling: blocks of 32 consecutive k share one E8M0 scale 2^e, e = floor(log2(max|v|)) - 8 (8 = emax of e4m3),
+// +1 when max|v| / 2^e > 448 (common.h, mx_shared_exponent); elements are v / 2^e rounded to nearest even into OCP e4m3. HBM-bound: reads 64 B, writes
 // 33 B per block; one lane per block, 16-byte accesses.
 #include "common.h"
 #include "kernels.h"

@@ -157,13 +157,15 @@ def act_fn(name: str, x: torch.Tensor) -> torch.Tensor:
 
 def mx_quantize_dequantize(x: torch.Tensor) -> torch.Tensor:
     """OCP Microscaling FP8 (e4m3, 32-element blocks along the last dim, E8M0 shared exponent floor(log2 amax) - 8,
-    saturating round-to-nearest-even) applied and undone: the values the MXFP8 mode's GEMMs multiply. No counterpart in
+    plus one when the scaled block maximum would exceed 448; round-to-nearest-even) applied and undone: the values the MXFP8 mode's GEMMs multiply. No counterpart in
     the reference (BASELINE.json configs[4] is this build's fp8 mode); used only to check that mode."""
     shp = x.shape
     v = x.float().reshape(-1, shp[-1] // 32, 32)
     amax = v.abs().amax(-1)
     _, ex = torch.frexp(amax)
-    e = (ex - 1 - 8).clamp(min=-127)
+    e = ex - 1 - 8
+    e = e + ((amax / torch.exp2(e.float())) > 448).to(e.dtype)  # smallest power-of-two scale under which nothing saturates
+    e = e.clamp(min=-127)
     e = torch.where(amax == 0, torch.full_like(e, -127), e)
     sc = torch.exp2(e.float())[..., None]
     q = (v / sc).clamp(-448, 448).to(torch.float8_e4m3fn).float()

@@ -1,6 +1,6 @@
 """GPU: MXFP8 mode (BASELINE.json configs[4], "fp8 MFMA encoder GEMMs"). The checker is a torch emulation of OCP
-Microscaling -- per 32-element block: shared exponent floor(log2 amax) - 8, elements scaled, saturated to +-448 and
-rounded to nearest even into float8_e4m3fn -- and an fp32 matmul on the de-quantised values, which is what the scaled
+Microscaling -- per 32-element block: shared exponent floor(log2 amax) - 8 (+1 when the scaled maximum would exceed
+448), elements scaled, saturated to +-448 and rounded to nearest even into float8_e4m3fn -- and an fp32 matmul on the de-quantised values, which is what the scaled
 MFMA computes exactly (products of fp8 values and power-of-two scales are exact in fp32; only the summation order differs)."""
 import pytest
 import torch
@@ -16,7 +16,9 @@ def emulate_quantize(x: torch.Tensor):
     v = x.float().reshape(rows, K // 32, 32)
     amax = v.abs().amax(-1)
     _, ex = torch.frexp(amax)  # amax = m * 2^ex, m in [0.5, 1)
-    e = (ex - 1 - 8).clamp(min=-127)
+    e = ex - 1 - 8
+    e = e + ((amax / torch.exp2(e.float())) > 448).to(e.dtype)  # smallest power-of-two scale without saturation
+    e = e.clamp(min=-127)
     e = torch.where(amax == 0, torch.full_like(e, -127), e)
     scaled = (v * torch.exp2(-e.float())[..., None]).clamp(-448, 448)
     q = scaled.to(torch.float8_e4m3fn)
