@@ -48,6 +48,17 @@ INFERENCE_KEYS: List[str] = ["model_id", "arch_specifier", "feature_fusion", "vi
                              "visual_feature_length"]
 
 
+class ModelCfg(dict):
+    """The resolved model config: a dict that also reads as attributes (`model_cfg.num_frames`), the way the reference's
+    draccus dataclass is used by its scripts (scripts/eval_mcq.py:152)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+
+
 def resolve_model_config(cfg: Dict) -> Dict:
     """`ModelConfig.get_choice_class("merv-base")(**cfg)` + `__post_init__` (load_vid.py:73-79, models.py:88-97):
     merv-base defaults under the given fields, and an int `num_frames` inflated to one entry per backbone."""
@@ -55,4 +66,4 @@ def resolve_model_config(cfg: Dict) -> Dict:
     out.update({k: v for k, v in cfg.items() if k not in ("vidlm_id", "type")})
     if isinstance(out["num_frames"], int):
         out["num_frames"] = [out["num_frames"]] * len(out["video_backbone_ids"])
-    return out
+    return ModelCfg(out)

@@ -40,6 +40,22 @@ def load_video(video_path: Union[str, Path, Tuple[torch.Tensor, float]], decode_
         ids = frame_indices(frames.shape[0], float(avg_fps), clip_start_sec, clip_end_sec, num_frames, end_frame)
         return frames[torch.as_tensor(ids, dtype=torch.long)].contiguous()
     path = Path(video_path)
+    if path.is_dir():  # directories of decoded frames (datasets.py:59-112): VLEP at 3 fps (*.jpg), ShareGPT (*.jpeg)
+        from PIL import Image
+        low = str(path).lower()
+        if "vlep" in low:
+            images = sorted(str(p) for p in path.glob("*.jpg"))
+            assert len(images) > 0, f"video directory contains no frames to load video - {path}"
+            ids = frame_indices(len(images), 3.0, clip_start_sec, clip_end_sec, num_frames, None)  # fps_in_dir = 3 (:63)
+        elif "sharegpt" in low:
+            images = sorted(str(p) for p in path.glob("*.jpeg"))
+            assert len(images) > 0, f"video directory contains no frames to load video - {path}"
+            ids = frame_indices(len(images), 1.0, 0.0, None, num_frames, len(images) - 1)  # np.linspace(0, N-1, n, dtype=int) (:96)
+        else:
+            raise NotImplementedError  # as the reference (:112)
+        # the reference decodes with cv2.imread + BGR->RGB; PIL decodes the same JPEG to the same RGB values
+        frames = np.stack([np.array(Image.open(images[int(i)]).convert("RGB")) for i in ids], 0)
+        return torch.from_numpy(frames).permute(0, 3, 1, 2).contiguous()
     if path.suffix == ".gif":
         from PIL import Image, ImageSequence
         im = Image.open(str(path))

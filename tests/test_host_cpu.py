@@ -305,3 +305,35 @@ def test_static_decoder_matches_hf_forward_cpu():
         # and generate_from_embeds cuts at the step where every row has produced EOS
         ids = bb.generate_from_embeds(emb, max_new_tokens=12, eos_token_id=int(out.logits[0, -1].argmax()), use_graph=False)
         assert 1 <= ids.shape[1] <= 12
+
+
+def test_load_video_frame_directories(tmp_path):
+    """datasets.py:59-112: VLEP directories are 3 fps *.jpg with the clip window, ShareGPT directories *.jpeg sampled over
+    the whole clip; anything else raises NotImplementedError, as the reference does."""
+    import numpy as np
+    from PIL import Image
+    from merv_amd.registry import resolve_model_config
+    from merv_amd.sampler import frame_indices
+    from merv_amd.video_io import load_video
+    vlep = tmp_path / "VLEP_clip_001"
+    vlep.mkdir()
+    for i in range(12):
+        Image.fromarray(np.full((6, 8, 3), 20 * i, dtype=np.uint8)).save(vlep / f"{i:05d}.jpg", quality=100)
+    out = load_video(str(vlep), clip_start_sec=1.0, clip_end_sec=3.0, num_frames=4)
+    want = frame_indices(12, 3.0, 1.0, 3.0, 4, None)  # linspace(3, min(11, 8), 4, dtype=int)
+    assert out.shape == (4, 3, 6, 8) and list(want) == [3, 4, 6, 8]
+    assert [int(round(float(v) / 20)) for v in out[:, 0, 0, 0]] == list(want)
+    sg = tmp_path / "sharegpt_x"
+    sg.mkdir()
+    for i in range(5):
+        Image.fromarray(np.full((4, 4, 3), 40 * i, dtype=np.uint8)).save(sg / f"{i}.jpeg", quality=100)
+    out = load_video(str(sg), num_frames=3)
+    assert [int(round(float(v) / 40)) for v in out[:, 0, 0, 0]] == [0, 2, 4]
+    other = tmp_path / "frames"
+    other.mkdir()
+    with pytest.raises(NotImplementedError):
+        load_video(str(other), num_frames=2)
+    cfg = resolve_model_config({"model_id": "merv-full", "num_frames": [16, 16, 32, 16]})
+    assert cfg.num_frames == cfg["num_frames"] == [16, 16, 32, 16] and cfg.model_id == "merv-full"
+    with pytest.raises(AttributeError):
+        cfg.no_such_field
