@@ -8,13 +8,19 @@
 // (dinov2_video.py:138, siglip.py:148, vivit.py:104, modeling_video.py:98-186,
 // nn_utils.py:25,330).
 //
-// Structure (cdna_hip_programming.md section 5): 128x128x64 block tile, 4 waves (2x2, 64x64 each),
-// v_mfma_f32_16x16x32_bf16, operands staged global->LDS by LDS-DMA (global_load_lds_dwordx4), two LDS
-// stages so tile t+1 is in flight while tile t is multiplied, counted vmcnt + raw s_barrier (never a
-// __syncthreads() while a DMA is outstanding). The LDS image is lane-linear (DMA constraint), so the bank
-// swizzle chunk ^= (row & 7) is applied to the per-lane *source* address and to the ds_read address
-// (section 5.4 rule 21). Operands are swapped (D^T = W * A^T) so that every lane ends up with 4 consecutive
-// n of one output row: bias / LayerScale / residual / store are then 8-16 byte vector accesses.
+// Kernels in this file (DESIGN.md section 4 has the measurements):
+//   gemm_bf16_8phase_kernel   256x256 tile, 8 waves (2x4, 128x64 each), two 64 KB LDS buffers, four phases per K-tile
+//                             with ping-pong wave groups; the bulk of every launch. MX = true: the same schedule on
+//                             MXFP8 operands (v_mfma_scale_f32_16x16x128_f8f6f4).
+//   gemm_bf16_kernel          BM x BN tile with an NSTAGE-deep LDS ring and one counted-vmcnt barrier per K-step:
+//                             256x128 / 3 stages / staggered half-blocks (remaining rows with many tiles, row-remapped
+//                             patch embedding), 128x128 / 4 stages (at most one block per CU), 128x128 / 2 stages.
+//   launch_gemm               plan: complete rounds of the chip -> eight-phase kernel, remaining rows -> smaller tile.
+// Common to all: v_mfma_f32_16x16x32_bf16, operands staged global->LDS by LDS-DMA (global_load_lds_dwordx4), counted
+// vmcnt + raw s_barrier (never a __syncthreads() while a DMA is outstanding). The LDS image is lane-linear (DMA
+// constraint), so the bank swizzle chunk ^= (row & 7) is applied to the per-lane *source* address and to the ds_read
+// address (cdna_hip_programming.md section 5.4 rule 21). Operands are swapped (D^T = W * A^T) so that every lane ends
+// up with 4 consecutive n of one output row; the epilogue transposes through LDS for 16-byte, full-row accesses.
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
