@@ -175,6 +175,8 @@ def main():
 
     from merv_amd import _lib
     lib = _lib.load()
+    if os.environ.get("MERV_GEMM_GROUP_M"):  # tuning hook: tile-order group size of every GEMM launch
+        lib.merv_debug_set_gemm_variant(int(os.environ["MERV_GEMM_GROUP_M"]) << 8)
     specs, path = build_path(device, concurrent=not args.sequential)
     if args.ln_fold:
         for enc in path.encoders:
