@@ -3,11 +3,18 @@
 bench.py -- fused visual tokens/s through the 4-encoder + projector + fusion path (merv-frozen / merv-full geometry,
 frames [16,16,32,16], bf16) on N MI355X. Contract: see the task statement; ONE JSON line on rank 0.
 
-  step      = one pass of the hot path (a4-a10: pixels resident in HBM -> fused [B,1024,4096] bf16) over one batch
-  value     = fused visual tokens / s, whole job (1024 tokens per video)
-  roofline  = the bf16 MFMA GEMM kernel (92 % of the path's FLOPs): algorithmic FLOPs (2MNK) of all its launches in K
-              steps / their summed HIP-event durations (events recorded by the library on the launch stream)
-  cpu_baseline = the CPU oracle (torch fp32) timed on this host on a bounded sample, extrapolated per layer
+  step         = one pass of the hot path (a4-a10: pixels resident in HBM -> fused [B,1024,4096] bf16) over one batch
+  value        = fused visual tokens / s, whole job (1024 tokens per video)
+  roofline     = the bf16 MFMA GEMM kernels (92 % of the path's FLOPs): algorithmic FLOPs (2MNK) of all their launches in
+                 K steps / their summed HIP-event durations (events recorded by the library on the launch stream)
+  parity       = ONE video pushed through the fp32 CPU oracle (every consumed block: 23 / 23 / 12 / 11) with the SAME
+                 weights and pixels the HIP path holds: rel-L2 and min per-token cosine of every encoder's tokens, every
+                 projector's output and the fused [1,1024,4096] tokens (N = 1 only)
+  cpu_baseline = the wall time of that same oracle run on this host's cores (no extrapolation)
+  e2e          = BASELINE.json's secondary metric: quick_start-shaped generate() (GPU frame transforms -> visual path ->
+                 Llama-2-7B-geometry prefill -> graph-replayed greedy decode), generated tokens / s (N = 1 only)
+  multi_gpu    = N > 1: besides the data-parallel headline, the (encoder, video, frame-range) unit placement with both RCCL
+                 exchanges timed in the same process group (BASELINE.json configs[2])
 """
 from __future__ import annotations
 
@@ -29,54 +36,49 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, c
 PEAK_FP8_TFLOPS = 5000.0  # dense MX-scaled fp8 (MI355X_MICROARCH.md, Matrix cores)
 LLM_DIM, FUSION_EMBED = 4096, 3072
 TOKENS_PER_VIDEO = 1024
+BACKBONE_IDS = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-google-b-all-no-cls-16frames",
+                "siglip-vit-b16-224px-all-no-cls"]  # merv/conf/models.py:106-113
+NUM_FRAMES = [16, 16, 32, 16]  # merv/conf/models.py:118
+TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_gemm_traffic.json"
 
 
-def device_random_weights(spec, seed, device):
-    """Seeded random-init weights of the named architecture, generated directly on the GPU (no checkpoints here)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    D, Mh = spec.dim, spec.mlp_dim
-
-    def rn(*shape, std=0.02):
-        return torch.randn(*shape, generator=g, device=device) * std
-
-    P = spec.s_out * (spec.t_out if spec.joint_space_time else 1)
-    W = {"patch_w": rn(D, spec.k_true, std=spec.k_true**-0.5), "pos": rn(P, D), "layers": []}
-    if spec.name != "languagebind":
-        W["patch_b"] = rn(D)
-    if spec.prefix_tokens:
-        W["prefix"] = rn(spec.prefix_tokens, D)
-    if spec.pre_ln:
-        W["pre_ln_w"], W["pre_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
-    if spec.final_ln:
-        W["final_ln_w"], W["final_ln_b"] = 1 + rn(D, std=0.1), rn(D, std=0.1)
-    for _ in range(spec.layers):
-        Lw = {"ln1_w": 1 + rn(D, std=0.1), "ln1_b": rn(D, std=0.1), "qkv_w": rn(3 * D, D, std=D**-0.5), "qkv_b": rn(3 * D),
-              "proj_w": rn(D, D, std=D**-0.5), "proj_b": rn(D), "ln2_w": 1 + rn(D, std=0.1), "ln2_b": rn(D, std=0.1),
-              "fc1_w": rn(Mh, D, std=D**-0.5), "fc1_b": rn(Mh), "fc2_w": rn(D, Mh, std=Mh**-0.5), "fc2_b": rn(D)}
-        if spec.layerscale:
-            Lw["ls1"], Lw["ls2"] = 0.5 + rn(D, std=0.2), 0.5 + rn(D, std=0.2)
-        if spec.temporal_frames:
-            Lw.update({"t_emb": rn(spec.temporal_frames, D, std=D**-0.5), "t_ln_w": 1 + rn(D, std=0.1),
-                       "t_ln_b": rn(D, std=0.1), "t_qkv_w": rn(3 * D, D, std=D**-0.5), "t_qkv_b": rn(3 * D),
-                       "t_proj_w": rn(D, D, std=D**-0.5), "t_proj_b": rn(D)})
-        W["layers"].append(Lw)
-    return W
-
-
-def build_path(device, concurrent=True):
+def build_models(device, concurrent=True, want_ref=False):
+    """The merv-full visual stack with seeded random-init weights of the named architectures, generated on the GPU (there
+    are no checkpoints here). GEMM weights are bf16-representable (the reference's parameters after
+    `vidlm.to(torch.bfloat16)`, scripts/quick_start.py:12), so the CPU copy handed to the oracle (`want_ref`) holds
+    exactly the values the kernels multiply. Returns (specs, backbones, path, ref | None)."""
+    from merv_amd.backbones import VIDEO_BACKBONES, random_weights, weights_to
     from merv_amd.encoder import merv_full_specs
     from merv_amd.projector import CrossAttentionAdapterLearnableQuery
     from merv_amd.visual_path import MervVisualPath
     specs = merv_full_specs()
-    enc_w = [device_random_weights(s, 1000 + i, device) for i, s in enumerate(specs)]
+    bbs, ref_enc = [], []
+    for i, (spec, bid, nf) in enumerate(zip(specs, BACKBONE_IDS, NUM_FRAMES)):
+        w = random_weights(spec, 1000 + i, device=device, bf16_exact=True)
+        bb = VIDEO_BACKBONES[bid]["cls"](bid, "resize-naive", num_frames=nf, weights=w, device=device, **VIDEO_BACKBONES[bid]["kwargs"])
+        assert bb.spec == spec, (bb.spec, spec)
+        bbs.append(bb)
+        if want_ref:
+            ref_enc.append(weights_to(w, "cpu"))
+        del w
     g = torch.Generator(device=device).manual_seed(77)
-    proj_w = [(torch.randn(LLM_DIM, s.dim, generator=g, device=device) * s.dim**-0.5,
+    proj_w = [((torch.randn(LLM_DIM, s.dim, generator=g, device=device) * s.dim**-0.5).to(torch.bfloat16).float(),
                torch.randn(LLM_DIM, generator=g, device=device) * 0.02) for s in specs]
     torch.manual_seed(1024)  # merv.py:87
     fusion = CrossAttentionAdapterLearnableQuery(embed_dim=FUSION_EMBED, llm_dim=LLM_DIM, token_length=TOKENS_PER_VIDEO,
                                                  averagetoken=True)
-    path = MervVisualPath(specs, enc_w, proj_w, fusion, device, concurrent_streams=concurrent)
-    del enc_w
+    path = MervVisualPath(specs, None, proj_w, fusion, device, concurrent_streams=concurrent,
+                          encoders=[bb.featurizer for bb in bbs])
+    ref = None
+    if want_ref:
+        from oracle.parity import fusion_state
+        ref = {"enc_W": ref_enc, "proj_W": [(w.cpu(), b.cpu()) for w, b in proj_w], "Fw": fusion_state(fusion)}
+    return specs, bbs, path, {"ref": ref, "proj_w": proj_w, "fusion": fusion}
+
+
+def build_path(device, concurrent=True):
+    specs, _, path, _ = build_models(device, concurrent)
     return specs, path
 
 
@@ -86,58 +88,82 @@ def synth_pixels(specs, n_videos, device, seed):
     return [torch.randn(s.pixel_shape(n_videos), generator=g, device=device).to(torch.bfloat16) for s in specs]
 
 
-def cpu_baseline(budget_layers=2, threads=None):
-    """Oracle (torch fp32) on ONE video through the whole path: patch embed, every consumed block of the four encoders
-    (weights for `budget_layers` blocks are generated and reused cyclically: timing does not depend on their values),
-    projectors and fusion -- about 10-15 s of CPU work on the GPU host. Thread count: torch's intra-op pool
-    degrades badly past ~16 threads on these shapes (measured on the 256-core GPU host: 16 threads 0.118 s, 64 threads
-    0.30 s, 256 threads 6.5 s for the same two SigLIP blocks), so the baseline uses min(cores, 16) and says so."""
-    from oracle import merv_oracle as O
+def parity_and_cpu_baseline(path, specs, ref, device, threads=None):
+    """One video through the HIP path and through the oracle on the SAME weights and pixels; the oracle run is also the
+    reported CPU baseline (its wall time). Thread count: torch's intra-op pool degrades badly past ~16 threads on these
+    shapes (measured on the 256-core GPU host: 16 threads 0.118 s, 64 threads 0.30 s, 256 threads 6.5 s for the same two
+    SigLIP blocks), so the baseline uses min(cores, 16) and says so."""
+    from oracle.parity import compare, reference_video
     ncores = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(ncores)
-    cfgs = O.merv_full_cfgs()
-    total = 0.0
-    projected = []
-    executed = skipped = 0
-    for i, cfg in enumerate(cfgs):
-        depth = cfg.layers
-        cfg_s = O.EncoderCfg(**{**cfg.__dict__, "layers": budget_layers})
-        W = O.random_encoder_weights(cfg_s, seed=i)
-        shape = (1, 3, cfg.frames, cfg.img, cfg.img) if cfg.pix_layout == "BCFHW" else (1, cfg.frames, 3, cfg.img, cfg.img)
-        pix = torch.randn(shape, generator=torch.Generator().manual_seed(i))
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            x = O.encoder_embed(pix, cfg_s, W)
-            t1 = time.perf_counter()
-            # every consumed block is executed (the timing does not depend on the weight values, so the generated
-            # blocks are reused cyclically); only if the host is so slow that the sample would pass ~45 s does the rest
-            # of an encoder fall back to per-block extrapolation, and the sample string says so
-            done = 0
-            for li in range(depth):
-                x = O.encoder_block(x, cfg_s, W["layers"][li % budget_layers])
-                done += 1
-                if total + (time.perf_counter() - t0) > 45.0 and done >= budget_layers:
-                    break
-            t2 = time.perf_counter()
-            executed += done
-            skipped += depth - done
-            tok = x[:, cfg.prefix_tokens:].reshape(1, -1, cfg.dim)
-            pw, pb = O.random_projector_weights(cfg.dim, LLM_DIM, seed=i)
-            t3 = time.perf_counter()
-            projected.append(O.projector_forward(tok, cfg.t_out, cfg.hp, 8, pw, pb))
-            t4 = time.perf_counter()
-        total += (t1 - t0) + (t2 - t1) / done * depth + (t4 - t3)
-    Fw = O.random_fusion_weights(LLM_DIM, FUSION_EMBED, seed=5)
-    with torch.no_grad():
+    pix = synth_pixels(specs, 1, device, seed=4242)
+    was = path.concurrent
+    path.concurrent = False
+    fused, w = path.forward(pix)
+    torch.cuda.synchronize()
+    path.concurrent = was
+    hip_tok = [path.buffers(i, 1)["tokens"].float().cpu() for i in range(len(specs))]
+    hip_proj = [path.buffers(i, 1)["proj"].float().cpu() for i in range(len(specs))]
+    hip_fused, hip_w = fused.float().cpu(), w.float().cpu()
+    res, secs = reference_video([p.float().cpu() for p in pix], specs, ref["enc_W"], ref["proj_W"], ref["Fw"])
+    par = {"encoders": {s.name: {"tokens": compare(hip_tok[i], res["tokens"][i]), "projected": compare(hip_proj[i], res["projected"][i])}
+                        for i, s in enumerate(specs)},
+           "fused": compare(hip_fused, res["fused"]),
+           "fusion_weights_max_abs_diff": round(float((hip_w - res["weights"]).abs().max()), 6),
+           "depth": "/".join(str(s.layers) for s in specs), "videos": 1,
+           "weights": "shared: generated once on the GPU (GEMM weights bf16-representable), copied to the host for the oracle",
+           "tolerance": {"rel_l2": TOL_REL_L2, "min_cos": TOL_MIN_COS}}
+    worst_rel = max([par["fused"]["rel_l2"]] + [v["tokens"]["rel_l2"] for v in par["encoders"].values()])
+    worst_cos = min([par["fused"]["min_cos"]] + [v["tokens"]["min_cos"] for v in par["encoders"].values()])
+    par["pass"] = bool(worst_rel <= TOL_REL_L2 and worst_cos >= TOL_MIN_COS)
+    cpu = {"value": round(TOKENS_PER_VIDEO / secs, 2), "unit": "visual-tokens/s", "cores": ncores, "kind": "port",
+           "sample": (f"1 video through the whole path, fp32 torch CPU oracle on the GPU path's own weights: patch embed, all consumed "
+                      f"blocks ({par['depth']}), projectors and fusion; {secs:.1f} s/video, nothing extrapolated")}
+    return par, cpu
+
+
+def e2e_generate(bbs, extras, device, new_tokens=64):
+    """BASELINE.json metric, part 2 ("e2e gen tok/s, merv-full 16-frame"): the quick_start flow (scripts/quick_start.py:11-24)
+    -- decoded uint8 clip -> frame-index selection -> GPU frame transforms -> visual path -> splice -> Llama-2-7B geometry
+    (random init, PyTorch-ROCm) prefill of 1024 + prompt tokens -> graph-replayed greedy decode of `new_tokens` tokens."""
+    from merv_amd.llm import LlamaBackbone, llama2_7b_config
+    from merv_amd.sampler import temporal_subsample
+    from merv_amd.vidlm import MERV
+    from merv_amd.video_io import load_video
+    llm = LlamaBackbone(llama2_7b_config(), device=device)
+    llm.config.eos_token_id = None  # random weights: never stop early
+    m = MERV(bbs, llm)
+    with torch.no_grad():  # the bench's projector / fusion parameters (module init seeds differ from build_models')
+        for p, (w, b) in zip(m.projectors, extras["proj_w"]):
+            p.projector.projector.weight.copy_(w)
+            p.projector.projector.bias.copy_(b)
+        m.feature_fusion.load_state_dict(extras["fusion"].state_dict())
+    clip = (torch.randint(0, 256, (300, 360, 640, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)), 29.97)
+    prompt = [1] + list(range(100, 124))  # BOS + 24 prompt tokens
+
+    def run():
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        O.fusion_forward(projected, Fw)
-        total += time.perf_counter() - t0
-    return {
-        "value": round(TOKENS_PER_VIDEO / total, 2), "unit": "visual-tokens/s", "cores": ncores, "kind": "port",
-        "sample": (f"1 video through the whole path, fp32 torch CPU oracle: patch embed, all consumed blocks (23/23/12/11; "
-                   f"{executed} executed" + (f", {skipped} extrapolated per block" if skipped else "") +
-                   f"), projectors and fusion; {total:.1f} s/video"),
-    }
+        out = m.generate(clip, prompt, NUM_FRAMES, max_new_tokens=new_tokens)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    run()  # warm-up: decoder graph capture, workspaces
+    times = [run() for _ in range(3)]
+    t, out = min(times, key=lambda x: x[0])
+    fr = load_video(clip, num_frames=max(NUM_FRAMES)).to(device)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    vv = [vb.video_transform(fr[temporal_subsample(fr.shape[0], max(NUM_FRAMES), nf)].contiguous())[None] for vb, nf in zip(bbs, NUM_FRAMES)]
+    torch.cuda.synchronize(); t_pre = time.perf_counter() - t0
+    m.encode(vv); torch.cuda.synchronize()
+    t0 = time.perf_counter(); m.encode(vv); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
+    res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init (PyTorch-ROCm SDPA prefill, "
+                   "hipGraph-replayed static-cache decode)",
+           "new_tokens": int(out.shape[1]), "total_s": round(t, 4), "generated_tok_per_s": round(out.shape[1] / t, 2),
+           "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": TOKENS_PER_VIDEO + len(prompt)}
+    del m, llm
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -154,12 +180,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
     ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "units"],
-                    help="N > 1: 'dp' = every rank runs the whole path on its own videos (independent units, no data-path "
-                         "collective; the weak-scaling form of configs[1]); 'units' = (encoder, video) units placed across "
-                         "ranks with an RCCL exchange of projected tokens before fusion (configs[2]'s encoder sharding)")
+                    help="what `value` measures at N > 1: 'dp' = every rank runs the whole path on its own videos (independent "
+                         "units, no data-path collective; the weak-scaling form of configs[1]); 'units' = (encoder, video, "
+                         "frame-range) units placed across ranks with an RCCL exchange of projected tokens before fusion "
+                         "(configs[2]'s encoder sharding). Either way the other forms are timed too and reported under "
+                         "config.multi_gpu.")
     ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "all_gather"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ln-fold", action="store_true", help="fold LN1 / LN2 into the qkv / fc1 GEMMs (exact algebra; opt-in)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (parity + cpu_baseline)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the e2e generate() leg")
+    ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the extra unit-placement timings")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; useful at --batch 1)")
     ap.add_argument("--mxfp8", action="store_true",
                     help="BASELINE.json configs[4] variant: block GEMMs on MXFP8 operands (NOT the headline bf16 metric; "
@@ -180,99 +209,142 @@ def main():
     torch.cuda.set_device(device)
 
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get("MERV_BENCH_FORCE_DISTRIBUTED") == "1"  # exercise the N>1 code path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+        print(f"[bench] rank {rank}: RCCL process group of {dist.get_world_size()} ranks, device {device}", file=sys.stderr, flush=True)
 
     from merv_amd import _lib
     lib = _lib.load()
     if os.environ.get("MERV_GEMM_GROUP_M"):  # tuning hook: tile-order group size of every GEMM launch
         lib.merv_debug_set_gemm_variant(int(os.environ["MERV_GEMM_GROUP_M"]) << 8)
-    specs, path = build_path(device, concurrent=not args.sequential)
-    if args.ln_fold:
-        for enc in path.encoders:
-            enc.enable_ln_fold()
+    single = world == 1 and not force_dist
+    want_ref = single and rank == 0 and not args.no_cpu_baseline and not args.mxfp8
+    specs, bbs, path, extras = build_models(device, concurrent=not args.sequential, want_ref=want_ref)
     if args.mxfp8:
         for enc in path.encoders:
             enc.enable_mxfp8()
     B = args.batch
     G = B * world
-
-    force_dist = os.environ.get("MERV_BENCH_FORCE_DISTRIBUTED") == "1"  # exercise the N>1 code path on one GPU
-    if world == 1 and force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
-    use_units = force_dist or (world > 1 and args.parallelism == "units")
-    if not use_units:
-        pixels = synth_pixels(specs, B, device, seed=rank)  # this rank's own videos
-        replay = path.capture(pixels) if args.graph else None
-
-        def step():
-            return replay() if (replay is not None and path.concurrent) else path.forward(pixels)
-    else:
-        from merv_amd.distributed import DistributedVisualPath
-        dpath = DistributedVisualPath(path, [s.flops_per_video() for s in specs], world, rank, B, exchange=args.exchange)
-        unit_pixels = dpath.synth_unit_pixels(specs, seed=1234)
-
-        def step():
-            return dpath.forward(unit_pixels)
+    multi = world > 1 or force_dist
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(out[0].float()).all()
+    def timed(step):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        assert torch.isfinite(out[0].float()).all()
+        return el
+
+    # ---- the forms of the step
+    pixels = synth_pixels(specs, B, device, seed=rank)  # this rank's own videos (dp)
+    replay = path.capture(pixels) if (args.graph and not multi) else None
+
+    def step_dp():
+        return replay() if (replay is not None and path.concurrent) else path.forward(pixels)
+
+    def make_units_step(exchange, n_videos=None, replicate=False):
+        from merv_amd.distributed import DistributedVisualPath
+        dpath = DistributedVisualPath(path, specs, world, rank, B if n_videos is None else None, exchange=exchange,
+                                      n_videos=n_videos, replicate_fusion=replicate)
+        up = dpath.synth_unit_pixels(seed=1234)
+        return (lambda: dpath.forward(up)), dpath
+
+    headline_units = multi and args.parallelism == "units"
+    if headline_units:
+        step, dpath = make_units_step(args.exchange)
+    else:
+        step = step_dp
+    elapsed = timed(step)
+
+    multi_gpu = None
+    if multi and not args.no_multi:
+        multi_gpu = {"ranks": world, "videos_per_rank": B}
+        multi_gpu["dp_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / (elapsed if not headline_units else timed(step_dp)), 1)
+        for ex in ("all_to_all", "all_gather"):
+            if headline_units and ex == args.exchange:
+                el, dp_ = elapsed, dpath
+            else:
+                st, dp_ = make_units_step(ex)
+                el = timed(st)
+            multi_gpu[f"units_{ex}_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / el, 1)
+            multi_gpu[f"units_{ex}_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
+        # latency placement (SURVEY 8e): ONE video spread over all ranks (LanguageBind by clip, DINOv2 / SigLIP by frame
+        # ranges, ViViT whole), projected rows all-gathered, every rank fuses (so each holds the tokens for its prefill)
+        st, dp_ = make_units_step("all_gather", n_videos=1, replicate=True)
+        el = timed(st)
+        multi_gpu["one_video_latency_ms"] = round(el / args.steps * 1e3, 3)
+        multi_gpu["one_video_plan"] = dp_.describe_plan()
+        multi_gpu["one_video_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
 
     # ---- roofline leg: the same K steps again with every GEMM launch bracketed by HIP events on its own stream.
     # Kernel durations are only well defined when kernels do not overlap, so this pass runs the encoders on ONE
     # stream (the throughput above is measured with concurrent streams and no events).
     roof = None
-    if not args.no_prof and world == 1 and not force_dist:
+    if not args.no_prof and single:
         was = path.concurrent
         path.concurrent = False
-        step(); torch.cuda.synchronize()
+        step_dp(); torch.cuda.synchronize()
         lib.merv_prof_reset()
         lib.merv_prof_enable(1)  # class 0: GEMM
         for _ in range(args.steps):
-            step()
+            step_dp()
         torch.cuda.synchronize()
         lib.merv_prof_enable(0)
         path.concurrent = was
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         lib.merv_prof_read(0, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
         if n.value:
+            peak = PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS
             achieved = fl.value / (ms.value * 1e-3) / 1e12
-            traffic = None
-            tf = ROOT / "profiles" / "r01_pmc_gemm_traffic.json"
-            if tf.exists():
+            traffic = traffic_source = None
+            tf = ROOT / PMC_TRAFFIC_FILE
+            if tf.exists() and not args.mxfp8 and B == 8:
                 try:
                     per_step = json.loads(tf.read_text()).get("hbm_bytes_per_step")
                     traffic = per_step / (n.value / args.steps) if per_step else None  # per GEMM call, like `achieved`
+                    traffic_source = (f"{PMC_TRAFFIC_FILE}: FETCH_SIZE x2 + WRITE_SIZE from the builder's separate rocprofv3 --pmc passes of "
+                                      "this command (committed file, NOT measured in this run)")
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_8phase_kernel + gemm_bf16_kernel for the remaining rows (every GEMM call of the step)",
-                    "achieved": round(achieved, 1), "peak": PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),
-                    "traffic": None if args.mxfp8 else traffic,
+            roof = {"bound": "mfma",
+                    "kernel": ("gemm_bf16_8phase_kernel<MX> on MXFP8 operands" if args.mxfp8 else "gemm_bf16_8phase_kernel + gemm_bf16_kernel") +
+                              " (every GEMM call of the step: patch embed, qkv / proj / fc1 / fc2, temporal qkv / proj, projectors)",
+                    "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "launches": n.value, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "flops_per_launch": round(fl.value / n.value / 1e9, 3), "flops_unit": "GFLOP",
                     "algorithmic_bytes_per_launch": round(by.value / n.value),
                     "gemm_ms_per_step": round(ms.value / args.steps, 3)}
         lib.merv_prof_reset()
+
+    parity = cpu = e2e = None
+    if rank == 0 and single:
+        if want_ref:
+            parity, cpu = parity_and_cpu_baseline(path, specs, extras["ref"], device)
+            extras["ref"] = None
+        if not args.no_e2e and not args.mxfp8:
+            e2e = e2e_generate(bbs, extras, device)
     if world > 1:
         dist.barrier()
 
@@ -281,6 +353,7 @@ def main():
         value = G * TOKENS_PER_VIDEO * args.steps / elapsed
         flops_video = sum(s.flops_per_video() + 2.0 * TOKENS_PER_VIDEO * s.dim * LLM_DIM for s in specs)  # + projectors
         path_tflops = flops_video * G * args.steps / elapsed / 1e12
+        peak = PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS
         line = {
             "metric": "fused visual tokens/s through 4-encoder+projector+fusion (merv-full geometry)",
             "value": round(value, 1), "unit": "visual-tokens/s", "n_gpus": world, "steps": args.steps,
@@ -291,19 +364,16 @@ def main():
                                     "merv-frozen 4 frozen encoders bf16 inference, frames [16,16,32,16], 224px "
                                     "(BASELINE.json configs[1])"),
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
-                       "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if args.graph else ""),
-                       "parallelism": ("single GPU" if world == 1 and not force_dist else
-                                       f"(encoder,video) units over {world} GPUs, RCCL {args.exchange} before fusion" if use_units else
+                       "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if replay is not None else ""),
+                       "parallelism": ("single GPU" if single else
+                                       f"(encoder, video, frame-range) units over {world} GPUs, RCCL {args.exchange} before fusion" if headline_units else
                                        f"data-parallel over videos on {world} GPUs, no data-path collective"),
-                       "path_tflops": round(path_tflops, 1),
-                       "path_frac_of_mfma_peak": round(path_tflops / (PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS), 4),
-                       "flops_per_video_T": round(flops_video / 1e12, 3)},
-            "roofline": roof,
+                       "path_tflops": round(path_tflops, 1), "path_frac_of_mfma_peak": round(path_tflops / peak, 4),
+                       "flops_per_video_T": round(flops_video / 1e12, 3),
+                       "e2e_gen_tok_s": e2e["generated_tok_per_s"] if e2e else None,
+                       "multi_gpu": multi_gpu},
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu, "e2e": e2e,
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        else:
-            line["cpu_baseline"] = None
         print(json.dumps(line), file=real_stdout, flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -118,6 +118,18 @@ int merv_encoder_forward(const merv_encoder *enc, const void *pixels, int32_t pi
                          void *out_tokens, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same forward over `frames` frames per video instead of the descriptor's count: a frame-range work unit of the
+ * multi-GPU placement (DINOv2 / SigLIP frames are independent sequences, dinov2_video.py:135-136,
+ * siglip.py:146-147; LanguageBind clips of `temporal_frames` frames are independent by construction,
+ * languagebind/video/modeling_video.py:140-146). pixels hold exactly `frames` frames per video in the encoder's layout;
+ * out_tokens is [B, frames/tubelet * S, D]. frames must be a multiple of the tubelet and of temporal_frames; a joint
+ * space-time encoder (ViViT) only accepts its own frame count. Workspace: merv_encoder_workspace_bytes(enc, batch) suffices
+ * for any frames <= the descriptor's.
+ */
+int merv_encoder_forward_frames(const merv_encoder *enc, const void *pixels, int32_t pix_dtype, int32_t batch,
+                                int32_t frames, void *out_tokens, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * AveragePooling3DProjector.forward with mlp_type="linear" (merv/util/nn_utils.py:320-330, :31-32):
  * tokens [B, T*S*S, C] -> AdaptiveAvgPool3d((T, out_size, out_size)) -> Linear(C -> llm_dim) -> [B, T*out^2, llm_dim].
  * pooled_ws: scratch of B*T*out^2*C bf16.

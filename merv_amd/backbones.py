@@ -83,13 +83,19 @@ class VideoBackbone(nn.Module):
         return torch.bfloat16
 
 
-def random_weights(spec: EncoderSpec, seed: int) -> Dict:
-    """Seeded synthetic parameters in canonical layout (fp32 CPU)."""
-    g = torch.Generator().manual_seed(seed)
+_BF16_STORED = ("patch_w", "pos", "prefix", "qkv_w", "proj_w", "fc1_w", "fc2_w", "t_qkv_w", "t_proj_w")
+
+
+def random_weights(spec: EncoderSpec, seed: int, device="cpu", bf16_exact: bool = False) -> Dict:
+    """Seeded synthetic parameters in canonical layout (fp32), generated on `device` (there are no checkpoints here).
+    `bf16_exact=True` rounds the tensors the HIP path stores in bf16 (GEMM weights, position / prefix rows) to
+    bf16-representable values, as the reference's `vidlm.to(torch.bfloat16)` (scripts/quick_start.py:12) does to its
+    parameters: a checker that is handed the same dict then sees exactly the values the kernels multiply."""
+    g = torch.Generator(device=device).manual_seed(seed)
     D, Mh = spec.dim, spec.mlp_dim
 
     def rn(*shape, std=0.02):
-        return torch.randn(*shape, generator=g) * std
+        return torch.randn(*shape, generator=g, device=device) * std
 
     P = spec.s_out * (spec.t_out if spec.joint_space_time else 1)
     out = {"patch_w": rn(D, spec.k_true, std=spec.k_true**-0.5), "pos": rn(P, D), "layers": []}
@@ -112,6 +118,18 @@ def random_weights(spec: EncoderSpec, seed: int) -> Dict:
                        "t_ln_b": rn(D, std=0.1), "t_qkv_w": rn(3 * D, D, std=D**-0.5), "t_qkv_b": rn(3 * D),
                        "t_proj_w": rn(D, D, std=D**-0.5), "t_proj_b": rn(D)})
         out["layers"].append(Lw)
+    if bf16_exact:
+        for d in [out] + out["layers"]:
+            for k in _BF16_STORED:
+                if k in d:
+                    d[k] = d[k].to(torch.bfloat16).float()
+    return out
+
+
+def weights_to(W: Dict, device) -> Dict:
+    """Copy of a canonical weight dict on `device` (e.g. to hand the parameters of a GPU-resident path to a host checker)."""
+    out = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in W.items() if k != "layers"}
+    out["layers"] = [{k: v.to(device) for k, v in L.items()} for L in W["layers"]]
     return out
 
 

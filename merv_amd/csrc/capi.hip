@@ -36,6 +36,35 @@ extern "C" int merv_abi_version(void) { return MERV_ABI_VERSION; }
         }                                                                               \
     } while (0)
 
+// Every entry point launches on the caller's stream. HIP launches go to the CURRENT device, which need not be the
+// stream's: make the stream's device current for the duration of the call (and restore it), so that a caller that
+// holds tensors on cuda:1 while cuda:0 is current gets correct launches instead of a foreign-device stream error.
+struct StreamDeviceGuard {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit StreamDeviceGuard(void* stream_) {
+        err = hipGetDevice(&prev);
+        if (err != hipSuccess) return;
+        dev = prev;
+        hipStream_t s = (hipStream_t)stream_;
+        if (s != nullptr) {  // the null stream always belongs to the current device
+            hipDevice_t d;
+            if (hipStreamGetDevice(s, &d) == hipSuccess) dev = (int)d;
+            else (void)hipGetLastError();  // e.g. a capturing stream on an older runtime: keep the current device
+        }
+        if (dev != prev) err = hipSetDevice(dev);
+    }
+    ~StreamDeviceGuard() {
+        if (dev != prev && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define MERV_STREAM_DEVICE(stream_)                                                   \
+    StreamDeviceGuard sdg__(stream_);                                                 \
+    if (sdg__.err != hipSuccess) {                                                    \
+        merv_set_error("could not make the stream's device current");                \
+        return 2;                                                                     \
+    }
+
 struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + block scales)
     const uint8_t *qkv_q, *qkv_s, *proj_q, *proj_s, *fc1_q, *fc1_s, *fc2_q, *fc2_s;
     const uint8_t *tqkv_q, *tqkv_s, *tproj_q, *tproj_s;  // LanguageBind temporal sub-block (null otherwise)
@@ -128,8 +157,8 @@ struct Workspace {
     float* stats;       // folded LayerNorm: {rstd, -mean * rstd} per row
     size_t total;
 };
-Workspace carve(const merv_encoder* e, int batch, char* base) {
-    const size_t M = (size_t)batch * e->seq_per_video * e->ntok;
+Workspace carve(const merv_encoder* e, int nseq, char* base) {
+    const size_t M = (size_t)nseq * e->ntok;
     const size_t D = e->d.dim;
     size_t hcols = e->d.mlp_dim;
     if ((size_t)e->d.k_pad > hcols) hcols = e->d.k_pad;  // im2col matrix aliases the MLP hidden buffer
@@ -173,6 +202,7 @@ extern "C" size_t merv_encoder_ln_fold_bytes(const merv_encoder* e) {
 }
 
 extern "C" int merv_encoder_enable_ln_fold(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(e && buf, "merv_encoder_enable_ln_fold: null argument");
     MERV_CHECK(bytes >= merv_encoder_ln_fold_bytes(e), "merv_encoder_enable_ln_fold: buffer too small");
     MERV_CHECK(((uintptr_t)buf & 255) == 0, "merv_encoder_enable_ln_fold: buffer must be 256-byte aligned");
@@ -212,6 +242,7 @@ extern "C" size_t merv_encoder_mxfp8_bytes(const merv_encoder* e) {
 }
 
 extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(e && buf, "merv_encoder_enable_mxfp8: null argument");
     const int D = e->d.dim, H = e->d.mlp_dim;
     MERV_CHECK(D % 256 == 0 && D >= 512 && H % 256 == 0 && H >= 512, "merv_encoder_enable_mxfp8: dim and mlp_dim must be multiples of 256, >= 512");
@@ -248,7 +279,7 @@ extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t byte
 
 extern "C" size_t merv_encoder_workspace_bytes(const merv_encoder* enc, int32_t batch) {
     if (!enc || batch <= 0) return 0;
-    return carve(enc, batch, nullptr).total;
+    return carve(enc, batch * enc->seq_per_video, nullptr).total;
 }
 
 static GemmArgs gemm_args(const bf16_t* A, int lda, const void* W, int K, bf16_t* C, int ldc, int M, int N,
@@ -262,26 +293,42 @@ static GemmArgs gemm_args(const bf16_t* A, int lda, const void* W, int K, bf16_t
 
 extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, int32_t pix_dtype, int32_t batch,
                                     void* out_tokens, void* workspace, size_t workspace_bytes, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(e, "merv_encoder_forward: null argument");
+    return merv_encoder_forward_frames(e, pixels, pix_dtype, batch, e->d.frames, out_tokens, workspace, workspace_bytes, stream_);
+}
+
+extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pixels, int32_t pix_dtype, int32_t batch,
+                                           int32_t frames, void* out_tokens, void* workspace, size_t workspace_bytes,
+                                           void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(e && pixels && out_tokens && workspace, "merv_encoder_forward: null argument");
     MERV_CHECK(batch > 0, "merv_encoder_forward: batch must be positive");
     MERV_CHECK(pix_dtype == MERV_DT_F32 || pix_dtype == MERV_DT_BF16, "merv_encoder_forward: bad pixel dtype");
     MERV_CHECK(((uintptr_t)workspace & 255) == 0, "merv_encoder_forward: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream_;
     const merv_encoder_desc& d = e->d;
-    Workspace ws = carve(e, batch, (char*)workspace);
+    // A frame-range unit: per-frame encoders treat every frame as its own sequence (LanguageBind: every clip of
+    // `temporal_frames` frames), so any such count runs with the same weights; a joint space-time encoder (ViViT) does not split.
+    MERV_CHECK(frames == d.frames || (!d.joint_space_time && frames >= 1 && frames % d.tubelet == 0 &&
+                                      (d.temporal_frames == 0 || frames % d.temporal_frames == 0)),
+               "merv_encoder_forward_frames: frames must equal the descriptor's count (joint space-time) or be whole clips / frames");
+    const int seq_per_video = d.joint_space_time ? 1 : frames / d.tubelet;
+    const int T_out = frames / d.tubelet;
+    Workspace ws = carve(e, batch * seq_per_video, (char*)workspace);
     MERV_CHECK(workspace_bytes >= ws.total, "merv_encoder_forward: workspace too small");
 
-    const int D = d.dim, nseq = batch * e->seq_per_video, ntok = e->ntok, M = nseq * ntok;
+    const int D = d.dim, nseq = batch * seq_per_video, ntok = e->ntok, M = nseq * ntok;
     const float scale = 0.125f;  // 1/sqrt(64)
 
     // ---- patch / tubelet embedding: im2col + GEMM (+bias +pos), rows scattered past the prefix tokens ----
     {
         Im2colArgs ic;
         ic.pix = pixels; ic.pix_is_bf16 = (pix_dtype == MERV_DT_BF16); ic.out = ws.h;
-        ic.B = batch; ic.frames = d.frames; ic.img = d.img; ic.patch = d.patch; ic.tt = d.tubelet; ic.kpad = d.k_pad;
+        ic.B = batch; ic.frames = frames; ic.img = d.img; ic.patch = d.patch; ic.tt = d.tubelet; ic.kpad = d.k_pad;
         const long long hw = (long long)d.img * d.img;
-        if (d.pix_layout == MERV_PIX_BCFHW) { ic.sB = 3LL * d.frames * hw; ic.sC = d.frames * hw; ic.sF = hw; }
-        else { ic.sB = 3LL * d.frames * hw; ic.sF = 3 * hw; ic.sC = hw; }
+        if (d.pix_layout == MERV_PIX_BCFHW) { ic.sB = 3LL * frames * hw; ic.sC = frames * hw; ic.sF = hw; }
+        else { ic.sB = 3LL * frames * hw; ic.sF = 3 * hw; ic.sC = hw; }
         MERV_HIP(launch_im2col(ic, s));
         GemmArgs g = gemm_args(ws.h, d.k_pad, e->w.patch_w, d.k_pad, ws.x, D, nseq * e->P, D, e->w.patch_b, ACT_NONE);
         g.res = (const bf16_t*)e->w.pos; g.ldres = D; g.res_row_mod = e->P;
@@ -382,10 +429,10 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
         src = ws.y;
     }
     GatherTokensArgs ga;
-    ga.x = src; ga.out = (bf16_t*)out_tokens; ga.B = batch; ga.T = e->T_out; ga.S = e->S_out; ga.D = D;
+    ga.x = src; ga.out = (bf16_t*)out_tokens; ga.B = batch; ga.T = T_out; ga.S = e->S_out; ga.D = D;
     ga.prefix = d.prefix_tokens;
     if (d.joint_space_time) { ga.bstride = ntok; ga.fstride = e->S_out; }
-    else { ga.bstride = e->seq_per_video * ntok; ga.fstride = ntok; }
+    else { ga.bstride = seq_per_video * ntok; ga.fstride = ntok; }
     MERV_HIP(launch_gather_tokens(ga, s));
     return 0;
 }
@@ -393,6 +440,7 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
 extern "C" int merv_projector_forward(const void* tokens, int32_t batch, int32_t T, int32_t S, int32_t C,
                                       int32_t out_size, const void* proj_w, const float* proj_b, int32_t llm_dim,
                                       void* pooled_ws, void* out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(tokens && proj_w && pooled_ws && out, "merv_projector_forward: null argument");
     MERV_CHECK(batch > 0 && T > 0 && S > 0 && out_size > 0 && S >= out_size, "merv_projector_forward: bad geometry");
     MERV_CHECK(C % 64 == 0 && llm_dim % 128 == 0, "merv_projector_forward: C % 64 and llm_dim % 128 required");
@@ -412,6 +460,7 @@ extern "C" size_t merv_fusion_workspace_floats(int32_t batch, int32_t E, int32_t
 
 extern "C" int merv_fusion_forward(const void* const* v, int32_t E, int32_t batch, int32_t T, int32_t C, const float* u,
                                    float* partial_ws, float* weights_out, void* out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(v && u && partial_ws && weights_out && out, "merv_fusion_forward: null argument");
     MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_forward: 1..8 encoders supported");
     MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_forward: bad geometry");
@@ -429,6 +478,7 @@ extern "C" int merv_fusion_forward(const void* const* v, int32_t E, int32_t batc
 
 extern "C" int merv_splice_forward(const void* emb, const void* vis, int32_t batch, int32_t S, int32_t T, int32_t C,
                                    int32_t bos, void* out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(emb && vis && out, "merv_splice_forward: null argument");
     MERV_CHECK(batch > 0 && S >= 0 && T >= 0 && C % 8 == 0 && bos >= 0 && bos <= S, "merv_splice_forward: bad geometry");
     SpliceArgs sa{(const bf16_t*)emb, (const bf16_t*)vis, (bf16_t*)out, batch, S, T, C, bos};
@@ -444,6 +494,7 @@ extern "C" size_t merv_fusion_backward_workspace_floats(int32_t batch, int32_t E
 
 extern "C" int merv_fusion_backward_reduce(const void* const* v, int32_t E, int32_t batch, int32_t T, int32_t C,
                                            const void* grad_out, float* ws, float* dw_out, float* vbar_out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(v && grad_out && ws && dw_out && vbar_out, "merv_fusion_backward_reduce: null argument");
     MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_backward_reduce: 1..8 encoders supported");
     MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_backward_reduce: bad geometry");
@@ -461,6 +512,7 @@ extern "C" int merv_fusion_backward_reduce(const void* const* v, int32_t E, int3
 
 extern "C" int merv_fusion_backward_mix(const void* grad_out, const float* weights, const float* ds, const float* u,
                                         int32_t E, int32_t batch, int32_t T, int32_t C, void* const* dv_out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(grad_out && weights && ds && u && dv_out, "merv_fusion_backward_mix: null argument");
     MERV_CHECK(E >= 1 && E <= 8, "merv_fusion_backward_mix: 1..8 encoders supported");
     MERV_CHECK(batch > 0 && T > 0 && C > 0 && C % 8 == 0, "merv_fusion_backward_mix: bad geometry");
@@ -486,6 +538,7 @@ extern "C" size_t merv_projector_backward_workspace_bytes(int32_t M, int32_t C, 
 
 extern "C" int merv_projector_backward(const void* grad_out, const void* pooled, int32_t M, int32_t C, int32_t llm, void* ws,
                                        size_t ws_bytes, void* grad_w, float* grad_b, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(grad_out && pooled && ws && grad_w && grad_b, "merv_projector_backward: null argument");
     MERV_CHECK(M > 0 && C > 0 && C % 128 == 0 && llm > 0 && llm % 8 == 0, "merv_projector_backward: need C % 128 == 0, llm % 8 == 0");
     MERV_CHECK(ws_bytes >= merv_projector_backward_workspace_bytes(M, C, llm), "merv_projector_backward: workspace too small");
@@ -512,6 +565,7 @@ extern "C" int merv_projector_backward(const void* grad_out, const void* pooled,
 
 extern "C" int merv_transpose_bf16(const void* in, int32_t R, int32_t C, int32_t ldi, void* out, int32_t ldo, int32_t Rpad,
                                    void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(in && out, "merv_transpose_bf16: null argument");
     MERV_CHECK(R > 0 && C > 0 && Rpad >= R && Rpad % 2 == 0 && ldi % 2 == 0 && ldo % 2 == 0 && ldi >= C && ldo >= Rpad,
                "merv_transpose_bf16: bad geometry (ldi, ldo, Rpad even; ldi >= C; ldo >= Rpad >= R)");
@@ -527,6 +581,7 @@ extern "C" size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K) {
 }
 
 extern "C" int merv_quantize_mxfp8(const void* x, int32_t rows, int32_t K, int32_t ld, void* q, void* scales, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(x && q && scales, "merv_quantize_mxfp8: null argument");
     MERV_CHECK(rows > 0 && K > 0 && K % 128 == 0 && ld % 8 == 0 && ld >= K, "merv_quantize_mxfp8: need K % 128 == 0, ld % 8 == 0, ld >= K");
     MxQuantArgs a{(const bf16_t*)x, (uint8_t*)q, (uint8_t*)scales, rows, K, ld};
@@ -537,6 +592,7 @@ extern "C" int merv_quantize_mxfp8(const void* x, int32_t rows, int32_t K, int32
 extern "C" int merv_gemm_mxfp8(const void* A8, const void* scale_a, const void* W8, const void* scale_w, void* C, const float* bias,
                                const float* lscale, const void* res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw,
                                int32_t ldc, int32_t ldres, int32_t act, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(A8 && scale_a && W8 && scale_w && C, "merv_gemm_mxfp8: null argument");
     MERV_CHECK(M > 0 && N > 0 && N % 256 == 0 && K >= 512 && K % 256 == 0, "merv_gemm_mxfp8: need N % 256 == 0, K % 256 == 0, K >= 512");
     MERV_CHECK(lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K && ldc % 8 == 0 && ldc >= N, "merv_gemm_mxfp8: bad leading dimension");
@@ -553,6 +609,7 @@ extern "C" int merv_gemm_mxfp8(const void* A8, const void* scale_a, const void* 
 // test hook: bf16 GEMM (automatic tile choice, incl. the split plan) whose epilogue writes MXFP8 instead of bf16
 extern "C" int merv_debug_gemm_mx_out(const void* A, const void* W, void* C_unused, int32_t M, int32_t N, int32_t K, void* q_out,
                                       void* scales_out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(A && W && q_out && scales_out, "merv_debug_gemm_mx_out: null argument");
     MERV_CHECK(N % 128 == 0 && K % 64 == 0, "merv_debug_gemm_mx_out: bad geometry");
     GemmArgs g = gemm_args((const bf16_t*)A, K, W, K, (bf16_t*)C_unused, N, M, N, nullptr, ACT_NONE);
@@ -570,6 +627,7 @@ extern "C" size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t 
 extern "C" int merv_preprocess_pil(const void* frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t filter,
                                    const float* mean3, const float* std3, void* out_pixels, int32_t out_dtype, void* resized_u8,
                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(frames_u8 && mean3 && std3 && workspace && (out_pixels || resized_u8), "merv_preprocess_pil: null argument");
     MERV_CHECK(T > 0 && H > 0 && W > 0 && out_size > 0, "merv_preprocess_pil: bad geometry");
     MERV_CHECK(filter == 0 || filter == 1, "merv_preprocess_pil: filter must be 0 (bilinear) or 1 (bicubic)");
@@ -583,6 +641,7 @@ extern "C" int merv_preprocess_pil(const void* frames_u8, int32_t T, int32_t H, 
 
 extern "C" int merv_preprocess_languagebind(const void* frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t flip,
                                             const float* mean3, const float* std3, void* out_pixels, int32_t out_dtype, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(frames_u8 && mean3 && std3 && out_pixels, "merv_preprocess_languagebind: null argument");
     MERV_CHECK(T > 0 && H > 0 && W > 0 && out_size > 0, "merv_preprocess_languagebind: bad geometry");
     MERV_CHECK(out_dtype == MERV_DT_F32 || out_dtype == MERV_DT_BF16, "merv_preprocess_languagebind: bad output dtype");
@@ -599,6 +658,7 @@ extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float
                               const void* res, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldw, int32_t ldc,
                               int32_t ldres, int32_t res_row_mod, int32_t out_group, int32_t out_stride, int32_t out_off,
                               int32_t act, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(A && W && C, "merv_gemm_bf16: null argument");
     MERV_CHECK(K > 0 && K % 64 == 0 && N > 0 && N % 128 == 0, "merv_gemm_bf16: K % 64 == 0 and N % 128 == 0 required");
     GemmArgs g;
@@ -612,6 +672,7 @@ extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float
 
 extern "C" int merv_layernorm(void* x, void* y, const float* gamma, const float* beta, const float* add, int32_t M,
                               int32_t D, int32_t add_div, int32_t add_mod, float eps, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(x && y && gamma && beta, "merv_layernorm: null argument");
     LayerNormArgs ln{(bf16_t*)x, (bf16_t*)y, gamma, beta, add, M, D, add_div, add_mod, eps};
     MERV_HIP(launch_layernorm(ln, (hipStream_t)stream_));
@@ -620,6 +681,7 @@ extern "C" int merv_layernorm(void* x, void* y, const float* gamma, const float*
 
 extern "C" int merv_attention(const void* qkv, void* out, int32_t nseq, int32_t L, int32_t heads, int32_t D, float scale,
                               void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(qkv && out, "merv_attention: null argument");
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)out, nseq, L, heads, D, scale};
     MERV_HIP(launch_attention(a, (hipStream_t)stream_));
@@ -628,6 +690,7 @@ extern "C" int merv_attention(const void* qkv, void* out, int32_t nseq, int32_t 
 
 extern "C" int merv_temporal_attention(const void* qkv, void* out, int32_t nclips, int32_t t, int32_t ntok, int32_t heads,
                                        int32_t D, float scale, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(qkv && out, "merv_temporal_attention: null argument");
     TemporalAttnArgs a{(const bf16_t*)qkv, (bf16_t*)out, nclips, t, ntok, heads, D, scale};
     MERV_HIP(launch_temporal_attention(a, (hipStream_t)stream_));
@@ -637,6 +700,7 @@ extern "C" int merv_temporal_attention(const void* qkv, void* out, int32_t nclip
 extern "C" int merv_im2col(const void* pix, int32_t pix_dtype, void* out, int32_t B, int32_t frames, int32_t img,
                            int32_t patch, int32_t tubelet, int32_t k_pad, int64_t sB, int64_t sF, int64_t sC,
                            void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(pix && out, "merv_im2col: null argument");
     Im2colArgs ic;
     ic.pix = pix; ic.pix_is_bf16 = (pix_dtype == MERV_DT_BF16); ic.out = (bf16_t*)out; ic.B = B; ic.frames = frames;
@@ -647,6 +711,7 @@ extern "C" int merv_im2col(const void* pix, int32_t pix_dtype, void* out, int32_
 
 extern "C" int merv_pool3d(const void* tokens, void* out, int32_t B, int32_t T, int32_t S, int32_t out_size, int32_t C,
                            void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(tokens && out, "merv_pool3d: null argument");
     PoolArgs pa{(const bf16_t*)tokens, (bf16_t*)out, B, T, S, out_size, C};
     MERV_HIP(launch_pool(pa, (hipStream_t)stream_));

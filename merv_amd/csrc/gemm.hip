@@ -653,16 +653,28 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     gemm_epilogue<WTM, WTN, REMAP, ACT, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
 }
 
+// Per-device state: hipFuncSetAttribute and the CU count belong to a device, and one process may drive several
+// (load_vid(device="cuda:1"), one path per GPU). The C ABI makes the stream's device current before any launch.
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) dev = 0;
+    return dev;
+}
+inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&done)[MAX_DEVICES]) {
+    const int dev = current_device();
+    if (done[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
 template <bool REMAP, int ACT, bool MX = false>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
     auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + 255) / 256, tilesN = a.N / 256;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), LDS, s, a);
     return hipGetLastError();
@@ -685,12 +697,8 @@ hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
     static_assert(LDS >= WM * WN * (BM / WM) * 128, "epilogue staging must fit in the stage ring");
     static_assert(!STAGGER || WM * WN == 8, "stagger pairs the two waves of each SIMD: 8-wave blocks only");
     auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT>;
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
+    if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.N / BN;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(WM * WN * 64), LDS, s, a);
     return hipGetLastError();
@@ -708,14 +716,14 @@ int g_gemm_variant = 0;
 int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
 int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+    static int n[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!n[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
     }
-    return n;
+    return n[dev];
 }
 
 // Tile choice (measured on MI355X, tools/gemm_bench.py): the 256x256 eight-phase kernel has by far the best in-round

@@ -2,117 +2,216 @@
 DistributedVisualPath: the visual path over N MI355X, one process per GPU, torch.distributed over RCCL/xGMI.
 
 The reference has no multi-GPU inference path for this branch (SURVEY.md section 2.1: the only collectives are FSDP's);
-this is the branch-parallel placement BASELINE.json's north_star asks for, generalised so that it stays balanced:
+this is the branch-parallel placement BASELINE.json's north_star asks for, generalised so that it stays balanced.
+NOT YET RUN ON MORE THAN ONE RANK OF REAL HARDWARE (no multi-GPU box was available to the builder): covered by
+world-size-2 gloo tests with a stand-in compute (tests/test_distributed_cpu.py) and by world-size-1 RCCL runs.
 
-  * work unit = (encoder e, video v) of the step's global batch of G = world * videos_per_rank videos; unit cost =
-    the encoder's FLOPs. `plan_units` (visual_path.py) gives every rank, per encoder, one contiguous run of videos,
-    so a rank runs at most one batched forward per encoder. With world=4, G=1 this degenerates to the north_star's
-    "one encoder per GPU"; larger batches even out the 6.4x LanguageBind/SigLIP cost ratio.
+  * work unit = (encoder e, videos [v0, v1), frames [f0, f1)) -- `plan_units` (visual_path.py). The independent pieces of
+    the path: whole videos for ViViT (joint space-time attention), clips of 8 frames for LanguageBind
+    (modeling_video.py:140-146), single frames for DINOv2 / SigLIP (dinov2_video.py:135-136). The 3davg projector pools
+    inside a frame only (nn_utils.py:320-330 with output_frames == T), so a frame range of an encoder yields exactly the
+    matching row range [f0/tt*64, f1/tt*64) of that video's projected [1024, llm] tokens.
+      - throughput form: G = world * videos_per_rank videos per step, video v is fused on rank v // videos_per_rank (the
+        rank whose LLM replica prefills it);
+      - latency form (`n_videos=1, replicate_fusion=True`): ONE video spread over all ranks, every rank receives all rows
+        and fuses, so each holds the fused tokens for its prefill (4 ranks: makespan 1.89 TFLOP vs 3.28 for one encoder per
+        GPU; 8 ranks: 1.64, the LanguageBind clip);
+      - `placement="per_encoder"`: the literal configs[2] form, encoder e on rank e % world.
   * every rank holds all encoder weights (1.75 GB bf16 of 288 GB HBM): placement never moves weights.
-  * exchange: each projected unit [1024, llm] bf16 (8.39 MB) must reach the rank that fuses video v (owner(v) =
-    v // videos_per_rank, the rank whose LLM replica prefills it).
-      - "all_to_all": one all_to_all_single; every unit travels exactly once over the direct xGMI link
-        between producer and owner (7 point-to-point links per GPU, no ring hop).
-      - "all_gather": the literal north_star collective; every rank receives everything (world x the bytes).
-    then every rank runs the fusion kernels for its own videos.
+  * exchange of projected rows (bf16, llm wide):
+      - "all_to_all": one all_to_all_single with uneven row splits; every row travels exactly once over the direct xGMI
+        link between producer and owner (7 point-to-point links per GPU, no ring hop);
+      - "all_gather": the literal north_star collective (all_gather_into_tensor of each rank's rows padded to the largest
+        rank's count); every rank receives everything (world x the bytes).
+    then every owner runs the fusion kernels for its videos.
 
-The compute object is injected (`local`: encode_project(e, pixels) and fuse(list)), so the placement / exchange
-logic is testable on CPU with the gloo backend and a stand-in compute (tests/test_distributed_cpu.py).
+The compute object is injected (`local`: encode_project(e, pixels, stream, frames=) and fuse(list)), so the placement /
+exchange logic is testable on CPU with the gloo backend and a stand-in compute.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
-from .visual_path import plan_units
+from .visual_path import plan_one_encoder_per_rank, plan_units
+
+Unit = Tuple[int, int, int, int, int]  # (e, v0, v1, f0, f1)
+
+
+def atom_frames(spec) -> int:
+    """Smallest independent frame count of an encoder (see plan_units)."""
+    if spec.joint_space_time:
+        return spec.frames
+    return spec.temporal_frames if spec.temporal_frames else spec.tubelet
 
 
 class DistributedVisualPath:
-    def __init__(self, local, costs: Sequence[float], world: int, rank: int, videos_per_rank: int,
-                 exchange: str = "all_to_all", group=None):
+    def __init__(self, local, specs: Sequence, world: int, rank: int, videos_per_rank: Optional[int] = None,
+                 exchange: str = "all_to_all", group=None, n_videos: Optional[int] = None, replicate_fusion: bool = False,
+                 placement: str = "balanced"):
         if exchange not in ("all_to_all", "all_gather"):
             raise ValueError(f"unknown exchange `{exchange}`")
-        self.local = local
-        self.world, self.rank, self.B = world, rank, videos_per_rank
-        self.G = world * videos_per_rank
-        self.E = len(costs)
-        self.exchange = exchange
-        self.group = group
-        self.plan = plan_units(costs, self.G, world)
-        self.my_units = self.plan[rank]
-        # flat unit order per producer rank: the order in which it lays units out in its send buffer,
-        # sorted by owner rank so that all_to_all_single can use contiguous splits
-        self.send_order: List[List[Tuple[int, int]]] = []  # per rank: [(e, v)] sorted by (owner, e, v)
-        for r in range(world):
-            units = [(e, v) for (e, v0, v1) in self.plan[r] for v in range(v0, v1)]
-            units.sort(key=lambda ev: (ev[1] // videos_per_rank, ev[0], ev[1]))
-            self.send_order.append(units)
-        self.send_splits = [sum(1 for (_, v) in self.send_order[rank] if v // videos_per_rank == o) for o in range(world)]
-        self.recv_splits = [sum(1 for (_, v) in self.send_order[p] if v // videos_per_rank == rank) for p in range(world)]
-        # where each of my videos' (e, v) lands in my receive buffer
-        self.recv_index: Dict[Tuple[int, int], int] = {}
-        pos = 0
-        for p in range(world):
-            for (e, v) in self.send_order[p]:
-                if v // videos_per_rank == rank:
-                    self.recv_index[(e, v)] = pos
-                    pos += 1
-        assert pos == self.E * self.B, "every (encoder, video) of my videos must arrive exactly once"
-        self.max_units = max(len(u) for u in self.send_order)
+        if placement not in ("balanced", "per_encoder"):
+            raise ValueError(f"unknown placement `{placement}`")
+        if replicate_fusion and exchange != "all_gather":
+            raise ValueError("replicate_fusion (every rank fuses every video) needs the all_gather exchange")
+        if (videos_per_rank is None) == (n_videos is None) and not replicate_fusion:
+            raise ValueError("give videos_per_rank (throughput form) or n_videos with replicate_fusion (latency form)")
+        self.local, self.specs = local, list(specs)
+        self.world, self.rank = world, rank
+        self.E = len(self.specs)
+        self.exchange, self.group, self.replicate = exchange, group, replicate_fusion
+        self.frames = [s.frames for s in self.specs]
+        self.G = n_videos if n_videos is not None else world * videos_per_rank
+        self.B = self.G if replicate_fusion else videos_per_rank  # videos this rank fuses
+        costs = [float(s.flops_per_video()) for s in self.specs]
+        if placement == "per_encoder":
+            self.plan = plan_one_encoder_per_rank(self.E, self.G, world, self.frames)
+        else:
+            self.plan = plan_units(costs, self.G, world, self.frames, [atom_frames(s) for s in self.specs])
+        self.my_units: List[Unit] = self.plan[rank]
+        self.T, self.C = local.T_vis, local.llm_dim
+        for e in range(self.E):
+            if (self.T * atom_frames(self.specs[e])) % self.frames[e]:
+                raise ValueError(f"encoder {e}: {self.T} projected rows do not split over atoms of {atom_frames(self.specs[e])} frames")
 
-    # ---- synthetic inputs: each rank only materialises the pixels of its own units -------------------------------
-    def synth_unit_pixels(self, specs, seed: int) -> List[torch.Tensor]:
+        # chunk = the rows one unit contributes to ONE video: (e, v, f0, f1); per producer rank, in send order
+        def chunks_of(r: int):
+            ch = [(e, v, f0, f1) for (e, v0, v1, f0, f1) in self.plan[r] for v in range(v0, v1)]
+            ch.sort(key=lambda c: (self.owner(c[1]), c[0], c[1], c[2]))
+            return ch
+
+        self.send_order = [chunks_of(r) for r in range(world)]
+        self.rows_sent = [sum(self.rows(c) for c in self.send_order[r]) for r in range(world)]
+        self.max_rows = max(self.rows_sent)
+        if not replicate_fusion:
+            self.send_splits = [sum(self.rows(c) for c in self.send_order[rank] if self.owner(c[1]) == o) for o in range(world)]
+            self.recv_splits = [sum(self.rows(c) for c in self.send_order[p] if self.owner(c[1]) == rank) for p in range(world)]
+        # where every chunk this rank fuses lands: all_to_all -> offset in the receive buffer; all_gather -> p * max_rows + offset
+        self.recv_at: List[Tuple[Tuple[int, int, int, int], int]] = []
+        pos_a2a = 0
+        for p in range(world):
+            off = 0
+            for c in self.send_order[p]:
+                if self.mine(c[1]):
+                    self.recv_at.append((c, pos_a2a if exchange == "all_to_all" else p * self.max_rows + off))
+                    pos_a2a += self.rows(c)
+                off += self.rows(c)
+        got = sum(self.rows(c) for c, _ in self.recv_at)
+        assert got == self.E * self.B * self.T, "every projected row of my videos must arrive exactly once"
+        self._bufs: Dict[str, torch.Tensor] = {}
+
+    # ---- geometry -----------------------------------------------------------------------------------------------
+    def owner(self, v: int) -> int:
+        return 0 if self.replicate else v // self.B
+
+    def mine(self, v: int) -> bool:
+        return True if self.replicate else self.owner(v) == self.rank
+
+    def rows(self, c) -> int:
+        e, _, f0, f1 = c
+        return self.T * (f1 - f0) // self.frames[e]
+
+    def row0(self, c) -> int:
+        e, _, f0, _ = c
+        return self.T * f0 // self.frames[e]
+
+    def exchange_bytes_per_rank(self) -> Dict[str, int]:
+        es = 2 if getattr(self.local, "dtype", torch.bfloat16) == torch.bfloat16 else 4
+        if self.exchange == "all_to_all":
+            sent = sum(s for o, s in enumerate(self.send_splits) if o != self.rank)
+            recv = sum(s for p, s in enumerate(self.recv_splits) if p != self.rank)
+        else:
+            sent = self.max_rows * (self.world - 1)
+            recv = self.max_rows * (self.world - 1)
+        return {"sent": sent * self.C * es, "received": recv * self.C * es}
+
+    def describe_plan(self) -> List[str]:
+        names = [getattr(s, "name", str(i)) for i, s in enumerate(self.specs)]
+        return ["rank %d: " % r + (", ".join(
+            f"{names[e]} v{v0}" + (f"-{v1 - 1}" if v1 - v0 > 1 else "") + ("" if (f0, f1) == (0, self.frames[e]) else f" f{f0}-{f1 - 1}")
+            for (e, v0, v1, f0, f1) in units) or "idle") for r, units in enumerate(self.plan)]
+
+    # ---- synthetic inputs: each rank only materialises the pixels of its own units; a video's pixels depend on
+    # (seed, e, v) alone, so every placement of the same global batch sees the same data ------------------------------
+    def synth_unit_pixels(self, seed: int, dtype=torch.bfloat16) -> List[torch.Tensor]:
         dev = self.local.device
         out = []
-        for (e, v0, v1) in self.my_units:
-            g = torch.Generator(device=dev).manual_seed(seed * 1000003 + e * 10007 + v0)
-            out.append(torch.randn(specs[e].pixel_shape(v1 - v0), generator=g, device=dev).to(torch.bfloat16))
+        for (e, v0, v1, f0, f1) in self.my_units:
+            s = self.specs[e]
+            vids = []
+            for v in range(v0, v1):
+                g = torch.Generator(device=dev).manual_seed(seed * 1000003 + e * 10007 + v)
+                vids.append(torch.randn(s.pixel_shape(1), generator=g, device=dev).to(dtype))
+            pix = torch.cat(vids, 0)
+            if (f0, f1) != (0, s.frames):
+                pix = (pix[:, :, f0:f1] if s.pix_layout == "BCFHW" else pix[:, f0:f1]).contiguous()
+            out.append(pix)
         return out
 
+    def _buf(self, name: str, rows: int) -> torch.Tensor:
+        t = self._bufs.get(name)
+        if t is None or t.shape[0] != max(rows, 1):
+            dt = getattr(self.local, "dtype", torch.bfloat16)
+            t = self._bufs[name] = torch.zeros(max(rows, 1), self.C, dtype=dt, device=self.local.device)
+        return t
+
     def forward(self, unit_pixels: Sequence[torch.Tensor]):
-        """unit_pixels[i] = pixels of self.my_units[i] (encoder e's layout, videos v0..v1).
-        Returns (fused [B, T, llm], weights [B, E]) for this rank's own videos."""
+        """unit_pixels[i] = pixels of self.my_units[i] (encoder e's layout, videos v0..v1, frames f0..f1 only).
+        Returns (fused [B, T, llm], weights [B, E]) for the videos this rank fuses."""
         local = self.local
-        produced: Dict[Tuple[int, int], torch.Tensor] = {}
+        if len(unit_pixels) != len(self.my_units):
+            raise ValueError(f"expected {len(self.my_units)} unit pixel tensors, got {len(unit_pixels)}")
+        produced: Dict[Tuple[int, int, int, int], torch.Tensor] = {}
         streams = getattr(local, "streams", None)
         main = torch.cuda.current_stream(local.device) if streams else None
         if streams:
             start = torch.cuda.Event()
             start.record(main)
-        for i, ((e, v0, v1), pix) in enumerate(zip(self.my_units, unit_pixels)):
+            used = {}
+        for (e, v0, v1, f0, f1), pix in zip(self.my_units, unit_pixels):
+            nf = None if (f0, f1) == (0, self.frames[e]) else f1 - f0
             if streams:
-                st = streams[i % len(streams)]
-                st.wait_event(start)
-                proj = local.encode_project(e, pix, st)
+                st = streams[e % len(streams)]  # units of one encoder share its workspace: same stream, in order
+                if e not in used:
+                    st.wait_event(start)
+                proj = local.encode_project(e, pix, st, frames=nf)
+                if len([u for u in self.my_units if u[0] == e]) > 1:
+                    with torch.cuda.stream(st):
+                        proj = proj.clone()  # the persistent per-shape buffer may be reused by this encoder's next unit
+                used[e] = st
+            else:
+                proj = local.encode_project(e, pix, frames=nf)
+            for j, v in enumerate(range(v0, v1)):
+                produced[(e, v, f0, f1)] = proj[j]
+        if streams:
+            for st in used.values():
                 ev = torch.cuda.Event()
                 ev.record(st)
                 main.wait_event(ev)
-            else:
-                proj = local.encode_project(e, pix)
-            for j, v in enumerate(range(v0, v1)):
-                produced[(e, v)] = proj[j]
-        T, Cc = local.T_vis, local.llm_dim
-        dt, dev = getattr(local, "dtype", torch.bfloat16), local.device
+        T, C = self.T, self.C
+        # ---- pack this rank's rows in send order
+        send = self._buf("send", self.rows_sent[self.rank] if self.exchange == "all_to_all" else self.max_rows)
+        off = 0
+        for c in self.send_order[self.rank]:
+            n = self.rows(c)
+            send[off:off + n].copy_(produced[c])
+            off += n
+        # ---- one collective
         if self.exchange == "all_to_all":
-            send = torch.empty(len(self.send_order[self.rank]), T, Cc, dtype=dt, device=dev)
-            for i, ev in enumerate(self.send_order[self.rank]):
-                send[i].copy_(produced[ev])
-            recv = torch.empty(self.E * self.B, T, Cc, dtype=dt, device=dev)
-            dist.all_to_all_single(recv, send, output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits,
-                                   group=self.group)
-            def fetch(e, v):
-                return recv[self.recv_index[(e, v)]]
+            recv = self._buf("recv", self.E * self.B * T)
+            dist.all_to_all_single(recv[: self.E * self.B * T], send[: self.rows_sent[self.rank]],
+                                   output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits, group=self.group)
         else:
-            send = torch.zeros(self.max_units, T, Cc, dtype=dt, device=dev)
-            for i, ev in enumerate(self.send_order[self.rank]):
-                send[i].copy_(produced[ev])
-            gathered = torch.empty(self.world * self.max_units, T, Cc, dtype=dt, device=dev)
-            dist.all_gather_into_tensor(gathered, send, group=self.group)
-            where = {ev: p * self.max_units + i for p in range(self.world) for i, ev in enumerate(self.send_order[p])}
-            def fetch(e, v):
-                return gathered[where[(e, v)]]
-        mine = range(self.rank * self.B, (self.rank + 1) * self.B)
-        V = [torch.stack([fetch(e, v) for v in mine], 0) for e in range(self.E)]
+            recv = self._buf("gathered", self.world * self.max_rows)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        # ---- scatter the chunks of my videos into V_e [B, T, llm]
+        V = [self._buf(f"V{e}", self.B * T).view(self.B, T, C) for e in range(self.E)]
+        v_base = 0 if self.replicate else self.rank * self.B
+        for c, at in self.recv_at:
+            e, v, _, _ = c
+            r0, n = self.row0(c), self.rows(c)
+            V[e][v - v_base, r0:r0 + n].copy_(recv[at:at + n])
         return local.fuse(V)

@@ -162,6 +162,7 @@ class HipEncoder:
         check(self._lib.merv_encoder_create(C.byref(desc), C.byref(ew), C.byref(handle)), "merv_encoder_create")
         self._handle = handle
         self._ws: Optional[torch.Tensor] = None
+        self._retired: List[torch.Tensor] = []
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -174,8 +175,9 @@ class HipEncoder:
         only and the GEMMs read the residual stream directly."""
         need = self._lib.merv_encoder_ln_fold_bytes(self._handle)
         self._fold_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
-        check(self._lib.merv_encoder_enable_ln_fold(self._handle, ptr(self._fold_buf), need,
-                                                    torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_ln_fold")
+        with torch.cuda.device(self.device):
+            check(self._lib.merv_encoder_enable_ln_fold(self._handle, ptr(self._fold_buf), need,
+                                                        torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_ln_fold")
         self._ws = None
         self.ln_fold = True
         return self
@@ -188,8 +190,9 @@ class HipEncoder:
         alive. Not the default: trades the bf16 tolerance for speed."""
         need = self._lib.merv_encoder_mxfp8_bytes(self._handle)
         self._mx_buf = torch.empty(need, dtype=torch.uint8, device=self.device)
-        check(self._lib.merv_encoder_enable_mxfp8(self._handle, ptr(self._mx_buf), need,
-                                                  torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_mxfp8")
+        with torch.cuda.device(self.device):
+            check(self._lib.merv_encoder_enable_mxfp8(self._handle, ptr(self._mx_buf), need,
+                                                      torch.cuda.current_stream(self.device).cuda_stream), "merv_encoder_enable_mxfp8")
         mask = sum(self.MX_GEMMS[g] for g in set(gemms))
         check(self._lib.merv_encoder_set_mxfp8_mask(self._handle, mask), "merv_encoder_set_mxfp8_mask")
         self._ws = None  # the workspace grows
@@ -199,27 +202,43 @@ class HipEncoder:
     def workspace(self, batch: int) -> torch.Tensor:
         need = self._lib.merv_encoder_workspace_bytes(self._handle, batch)
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"{self.spec.name}: workspace would grow inside a graph capture; warm up this batch size first")
+            if self._ws is not None:
+                self._retired.append(self._ws)  # a side stream may still be running in it: never hand it back to the allocator
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def pixel_shape(self, batch: int, frames: Optional[int] = None):
+        s = self.spec
+        f = s.frames if frames is None else frames
+        return (batch, 3, f, s.img, s.img) if s.pix_layout == "BCFHW" else (batch, f, 3, s.img, s.img)
+
     def forward(self, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
-                stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
-        """pixels in the spec's layout (fp32 or bf16, contiguous, on this device) -> [B, num_patches, D] bf16."""
+                stream: Optional[torch.cuda.Stream] = None, frames: Optional[int] = None) -> torch.Tensor:
+        """pixels in the spec's layout (fp32 or bf16, contiguous, on this device) -> [B, num_patches, D] bf16.
+        `frames`: run on that many frames per video instead of the spec's count (merv_encoder_forward_frames: a
+        frame-range unit; per-frame encoders only, LanguageBind in whole clips)."""
         spec = self.spec
         if pixels.device != self.device:
             raise ValueError(f"{spec.name}: pixels on {pixels.device}, encoder on {self.device}")
         B = pixels.shape[0]
-        if tuple(pixels.shape) != spec.pixel_shape(B):
-            raise ValueError(f"{spec.name}: pixel shape {tuple(pixels.shape)} != {spec.pixel_shape(B)}")
+        if tuple(pixels.shape) != self.pixel_shape(B, frames):
+            raise ValueError(f"{spec.name}: pixel shape {tuple(pixels.shape)} != {self.pixel_shape(B, frames)}")
         if pixels.dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"{spec.name}: pixels must be fp32 or bf16")
         pixels = pixels.contiguous()
-        if out is None:
-            out = torch.empty(B, spec.num_patches, spec.dim, dtype=torch.bfloat16, device=self.device)
-        ws = self.workspace(B)
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = self._lib.merv_encoder_forward(
-            self._handle, ptr(pixels), DT_BF16 if pixels.dtype == torch.bfloat16 else DT_F32, B, ptr(out), ptr(ws),
-            ws.numel(), s.cuda_stream)
+        f = spec.frames if frames is None else frames
+        n_out = (f // spec.tubelet) * spec.s_out
+        with torch.cuda.device(self.device):  # the library launches on the CURRENT HIP device: make it this encoder's
+            if out is None:
+                out = torch.empty(B, n_out, spec.dim, dtype=torch.bfloat16, device=self.device)
+            elif tuple(out.shape) != (B, n_out, spec.dim) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+                raise ValueError(f"{spec.name}: out must be a contiguous bf16 {(B, n_out, spec.dim)} tensor")
+            ws = self.workspace(B)
+            s = stream if stream is not None else torch.cuda.current_stream(self.device)
+            rc = self._lib.merv_encoder_forward_frames(
+                self._handle, ptr(pixels), DT_BF16 if pixels.dtype == torch.bfloat16 else DT_F32, B, f, ptr(out), ptr(ws),
+                ws.numel(), s.cuda_stream)
         check(rc, f"merv_encoder_forward[{spec.name}]")
         return out

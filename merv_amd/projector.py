@@ -84,11 +84,12 @@ class AveragePooling3DProjector(nn.Module):
         w, b = self._dev
         llm = w.shape[0]
         T, o = Fr, self.output_size
-        pooled = torch.empty(B * T * o * o, Cc, dtype=torch.bfloat16, device=x.device)
-        if out is None:
-            out = torch.empty(B, T * o * o, llm, dtype=torch.bfloat16, device=x.device)
-        rc = _lib.load().merv_projector_forward(ptr(x), B, T, H, Cc, o, ptr(w), ptr(b), llm, ptr(pooled), ptr(out),
-                                                _stream_ptr(x.device))
+        with torch.cuda.device(x.device):
+            pooled = torch.empty(B * T * o * o, Cc, dtype=torch.bfloat16, device=x.device)
+            if out is None:
+                out = torch.empty(B, T * o * o, llm, dtype=torch.bfloat16, device=x.device)
+            rc = _lib.load().merv_projector_forward(ptr(x), B, T, H, Cc, o, ptr(w), ptr(b), llm, ptr(pooled), ptr(out),
+                                                    _stream_ptr(x.device))
         check(rc, "merv_projector_forward")
         return out
 
@@ -123,7 +124,10 @@ class CrossAttentionAdapterLearnableQuery(nn.Module):
     def prepare(self, device) -> None:
         self._u = self.fold().to(device).contiguous()
 
-    def forward(self, V: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, V: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None, partial: Optional[torch.Tensor] = None,
+                weights: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """nn_utils.py:487-521 -> (sum_e w_e V_e [B,T,C] bf16, w [B,E] fp32). `out` / `partial` / `weights`: caller-owned
+        result and scratch buffers (MervVisualPath keeps them persistent); allocated here when omitted."""
         for emb in V:  # nn_utils.py:494-495
             assert emb.shape[1] == self.token_length or emb.shape[1] == 1, (self.token_length, [e.shape for e in V])
         V = [(emb.repeat(1, self.token_length, 1) if emb.shape[1] == 1 else emb) for emb in V]
@@ -136,13 +140,19 @@ class CrossAttentionAdapterLearnableQuery(nn.Module):
         if self._u is None or self._u.device != dev:
             self.prepare(dev)
         lib = _lib.load()
-        partial = torch.empty(lib.merv_fusion_workspace_floats(B, E, T), dtype=torch.float32, device=dev)
-        weights = torch.empty(B, E, dtype=torch.float32, device=dev)
-        if out is None:
-            out = torch.empty(B, T, Cc, dtype=torch.bfloat16, device=dev)
-        arr = (C.c_void_p * E)(*[ptr(v) for v in Vc])
-        rc = lib.merv_fusion_forward(arr, E, B, T, Cc, ptr(self._u), ptr(partial), ptr(weights), ptr(out),
-                                     _stream_ptr(dev))
+        need = lib.merv_fusion_workspace_floats(B, E, T)
+        with torch.cuda.device(dev):
+            if partial is None:
+                partial = torch.empty(need, dtype=torch.float32, device=dev)
+            elif partial.numel() < need or partial.dtype != torch.float32:
+                raise ValueError("fusion: partial workspace too small")
+            if weights is None:
+                weights = torch.empty(B, E, dtype=torch.float32, device=dev)
+            if out is None:
+                out = torch.empty(B, T, Cc, dtype=torch.bfloat16, device=dev)
+            arr = (C.c_void_p * E)(*[ptr(v) for v in Vc])
+            rc = lib.merv_fusion_forward(arr, E, B, T, Cc, ptr(self._u), ptr(partial), ptr(weights), ptr(out),
+                                         _stream_ptr(dev))
         check(rc, "merv_fusion_forward")
         return out, weights
 
@@ -153,8 +163,9 @@ def splice(input_embeddings: torch.Tensor, fused: torch.Tensor, bos_token_length
     vis = fused.to(torch.bfloat16).contiguous()
     B, S, Cc = emb.shape
     T = vis.shape[1]
-    out = torch.empty(B, S + T, Cc, dtype=torch.bfloat16, device=emb.device)
-    rc = _lib.load().merv_splice_forward(ptr(emb), ptr(vis), B, S, T, Cc, bos_token_length, ptr(out),
-                                         _stream_ptr(emb.device))
+    with torch.cuda.device(emb.device):
+        out = torch.empty(B, S + T, Cc, dtype=torch.bfloat16, device=emb.device)
+        rc = _lib.load().merv_splice_forward(ptr(emb), ptr(vis), B, S, T, Cc, bos_token_length, ptr(out),
+                                             _stream_ptr(emb.device))
     check(rc, "merv_splice_forward")
     return out

@@ -155,28 +155,12 @@ def fold_query(fusion: CrossAttentionAdapterLearnableQuery) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------------
 def encode_trainable(vidlm: MERV, video_values: Sequence[torch.Tensor]):
     """Encoders forward-only on their streams, then projector / fusion with gradients. Returns (fused, weights|None)."""
-    dev = video_values[0].device
-    main = torch.cuda.current_stream(dev)
-    if vidlm.concurrent and not vidlm._streams:
-        vidlm._streams = [torch.cuda.Stream(dev) for _ in vidlm.video_backbones]
-    feats = []
+    # a4-a8 through the one orchestration (MervVisualPath: four encoder streams, persistent buffers); the tokens are
+    # cloned because autograd keeps them until backward while the path's buffers are reused by the next forward
     with torch.no_grad():
-        start = torch.cuda.Event()
-        start.record(main)
-        for i, (vb, pix) in enumerate(zip(vidlm.video_backbones, video_values)):
-            st = vidlm._streams[i] if vidlm.concurrent else main
-            if vidlm.concurrent:
-                st.wait_event(start)
-            with torch.cuda.stream(st):
-                f = vb(pix, None)
-                f = f.reshape(-1, vb.temporal_resolution, vb.spatial_resolution, f.shape[-1])
-                if vidlm.concurrent:
-                    f.record_stream(main)
-            feats.append(f)
-            if vidlm.concurrent:
-                done = torch.cuda.Event()
-                done.record(st)
-                main.wait_event(done)
+        toks = vidlm.visual_path(video_values[0].device).encode_tokens(video_values)
+        feats = [t.clone().reshape(-1, vb.temporal_resolution, vb.spatial_resolution, t.shape[-1])  # merv.py:576-585
+                 for t, vb in zip(toks, vidlm.video_backbones)]
     projected = []
     for f, proj in zip(feats, vidlm.projectors):
         lin = proj.projector.projector
@@ -221,7 +205,8 @@ def training_forward(vidlm: MERV, input_ids: torch.Tensor, attention_mask: torch
     if multimodal_indices is None:  # merv.py:543-545
         multimodal_indices = torch.arange(len(input_ids), dtype=torch.long, device=input_ids.device)
     if len(multimodal_indices) == 0:  # merv.py:548-561: plain language-model forward
-        out = llm.llm(input_ids=input_ids, attention_mask=attention_mask, labels=labels)
+        with torch.autocast("cuda", dtype=torch.bfloat16):  # same mixed-precision context as the multimodal branch
+            out = llm.llm(input_ids=input_ids, attention_mask=attention_mask, labels=labels)
         return out.loss, out.logits, None
     bos = 1 if getattr(llm.config, "bos_token_id", None) is not None else 0
     fused, w = encode_trainable(vidlm, [v[multimodal_indices] for v in video_values])  # merv.py:563-566

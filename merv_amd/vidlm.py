@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .backbones import VideoBackbone
 from .projector import AveragePooling3DProjector, CrossAttentionAdapterLearnableQuery, splice
+from .visual_path import MervVisualPath
 
 IGNORE_INDEX = -100
 
@@ -58,7 +59,8 @@ class MERVVisual(nn.Module):
         else:
             raise NotImplementedError(f'feature_fusion "{feature_fusion}" is not wired on the HIP path')
         self.concurrent = concurrent_streams and len(self.video_backbones) > 1
-        self._streams: List[torch.cuda.Stream] = []
+        self._path: Optional[MervVisualPath] = None
+        self._path_versions = None
 
     # -- checkpoint layout of the reference: {"model": {"projectors": {...}, "feature_fusion": {...}, "llm_backbone": ...}}
     def load_from_checkpoint_dict(self, model_state_dict: Dict) -> None:
@@ -74,41 +76,46 @@ class MERVVisual(nn.Module):
             self.feature_fusion._u = None
         for p in self.projectors:
             p._dev = None
+        self._path = None  # the path holds bf16 device copies of the projector weights and the folded fusion vector
+
+    # -- the ONE orchestration of the visual path (merv_amd/visual_path.py): built lazily from this module's backbones,
+    #    projectors and fusion module; rebuilt when their parameters change (checkpoint load, .to())
+    def _param_versions(self):
+        ps = [q for p in self.projectors for q in p.parameters()]
+        if self.feature_fusion is not None:
+            ps += list(self.feature_fusion.parameters())
+        return tuple((q.data_ptr(), q._version) for q in ps)
+
+    def visual_path(self, device=None) -> MervVisualPath:
+        dev = torch.device(device) if device is not None else self.video_backbones[0].featurizer.device
+        ver = self._param_versions()  # in-place updates (optimizer steps, load_state_dict) bump Tensor._version
+        if self._path is None or self._path.device != dev or ver != self._path_versions:
+            proj_w = [(p.projector.projector.weight, p.projector.projector.bias) for p in self.projectors]
+            if self.feature_fusion is not None:
+                self.feature_fusion._u = None
+            if self._path is not None and self._path.device == dev:
+                self._path.set_parameters(proj_w, self.feature_fusion)  # keep workspaces and buffers
+            else:
+                self._path = MervVisualPath([vb.spec for vb in self.video_backbones], None, proj_w, self.feature_fusion, dev,
+                                            out_size=self.projectors[0].output_size, concurrent_streams=self.concurrent,
+                                            encoders=[vb.featurizer for vb in self.video_backbones])
+            self._path_versions = ver
+        return self._path
+
+    def _apply(self, fn, *args, **kw):  # .to() / .bfloat16() / .cuda(): device copies held by the path go stale
+        self._path = None
+        return super()._apply(fn, *args, **kw)
 
     @torch.no_grad()
     def encode(self, video_values: Sequence[torch.Tensor]) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-        """merv.py:562-612: encoders -> [B,T,S,C] -> projectors -> fusion. Returns (fused [B, L, llm], weights [B,E]|None)."""
+        """merv.py:562-612: encoders -> [B,T,S,C] -> projectors -> fusion. Returns (fused [B, L, llm], weights [B,E]|None).
+        Runs MervVisualPath.forward -- the same code bench.py times: persistent per-(encoder, batch) buffers, four encoder
+        streams, no per-call allocation. The returned tensors are the path's buffers (overwritten by the next call)."""
         if len(video_values) != len(self.video_backbones):
             raise RuntimeError("Invalid `forward()` call!")  # merv.py:540-541
-        dev = video_values[0].device
-        main = torch.cuda.current_stream(dev)
-        if self.concurrent and not self._streams:
-            self._streams = [torch.cuda.Stream(dev) for _ in self.video_backbones]
-        projected = []
-        start = torch.cuda.Event()
-        start.record(main)
-        for i, (vb, proj, pix) in enumerate(zip(self.video_backbones, self.projectors, video_values)):
-            st = self._streams[i] if self.concurrent else main
-            if self.concurrent:
-                st.wait_event(start)
-            with torch.cuda.stream(st):
-                feats = vb(pix, None)  # [B, T*S, C]
-                feats = feats.reshape(-1, vb.temporal_resolution, vb.spatial_resolution, feats.shape[-1])  # :576-585
-                out = proj(feats)
-                if self.concurrent:
-                    feats.record_stream(st)
-                    out.record_stream(main)
-            projected.append(out)
-            if self.concurrent:
-                done = torch.cuda.Event()
-                done.record(st)
-                main.wait_event(done)
-        if self.feature_fusion_type is None:
-            if len(projected) != 1:
-                raise TypeError("argument of type 'NoneType' is not iterable")  # reference behaviour, merv.py:607 (App. B.4)
-            return projected[0], None
-        fused, w = self.feature_fusion(projected)
-        return fused, w
+        if self.feature_fusion_type is None and len(self.video_backbones) != 1:
+            raise TypeError("argument of type 'NoneType' is not iterable")  # reference behaviour, merv.py:607 (App. B.4)
+        return self.visual_path(video_values[0].device).forward(video_values)
 
     @torch.no_grad()
     def forward_visual(self, video_values: Sequence[torch.Tensor], input_embeddings: torch.Tensor,

@@ -2,14 +2,20 @@
 MervVisualPath: the visual branch of MERV.forward (merv/models/vidlms/merv.py:562-609) on MI355X --
 E encoders -> reshape [B,T,S,C] -> 3davg+linear projectors -> cross-encoder fusion -> [B, 1024, llm] fused tokens.
 
+This is the ONE orchestration of the path: `bench.py`, `MERVVisual.encode` / `MERV.generate` (merv_amd/vidlm.py), the
+hipGraph capture and the multi-GPU placement (merv_amd/distributed.py) all run through it. Every buffer a step touches
+(encoder workspace, encoder tokens, pooled rows, projected tokens, fusion partials / weights / output) is persistent
+per (encoder, batch): a step performs no allocation and needs no cross-stream lifetime bookkeeping.
+
 Single GPU: the encoders are independent until fusion (merv.py:563-566 is a list comprehension with no cross-talk),
 so each runs on its own HIP stream, event-joined before the fusion kernels (the reference runs them one after the
 other on one stream).
 
-Multi GPU (torch.distributed over RCCL/xGMI, one process per GPU): the (encoder, video) work units of a global batch
-are placed on ranks by an LPT schedule over their FLOP cost (every rank holds all encoder weights: 1.75 GB bf16 of
-288 GB); each rank projects its units and ONE all-gather of the projected [*, 1024, llm] bf16 tokens hands every
-rank the full V_e tensors, after which every rank fuses the videos it owns. See `plan_units`.
+Multi GPU (torch.distributed over RCCL/xGMI, one process per GPU; merv_amd/distributed.py): work units
+(encoder, video range, frame range) of a global batch are placed on ranks by `plan_units` (greedy contiguous fill over
+their FLOP cost; every rank holds all encoder weights: 1.75 GB bf16 of 288 GB); each rank projects its units, ONE
+collective (`all_to_all_single` by default, `all_gather_into_tensor` as the literal north_star form) moves the
+projected [*, 64 rows per frame, llm] bf16 tokens to the rank that fuses the video.
 """
 from __future__ import annotations
 
@@ -25,81 +31,162 @@ from .projector import CrossAttentionAdapterLearnableQuery
 
 
 class MervVisualPath:
-    def __init__(self, specs: Sequence[EncoderSpec], enc_weights: Sequence[Dict],
-                 proj_weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], fusion: CrossAttentionAdapterLearnableQuery,
-                 device, out_size: int = 8, concurrent_streams: bool = True):
+    def __init__(self, specs: Sequence[EncoderSpec], enc_weights: Optional[Sequence[Dict]],
+                 proj_weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                 fusion: Optional[CrossAttentionAdapterLearnableQuery], device, out_size: int = 8,
+                 concurrent_streams: bool = True, encoders: Optional[Sequence[HipEncoder]] = None):
+        """`encoders`: already-resident HipEncoder objects (then `enc_weights` is ignored), else one is built per
+        (spec, weight dict). `fusion=None` is the single-encoder form (merv.py:607: no fusion module): forward returns
+        the lone projector's output and weights None."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("MervVisualPath needs a ROCm device; merv_amd has no CPU path")
         self.lib = _lib.load()
         self.specs = list(specs)
-        self.encoders = [HipEncoder(s, w, self.device) for s, w in zip(specs, enc_weights)]
-        self.proj = [(w.detach().to(self.device, torch.bfloat16).contiguous(),
-                      b.detach().to(self.device, torch.float32).contiguous()) for w, b in proj_weights]
-        self.llm_dim = self.proj[0][0].shape[0]
-        self.out_size = out_size
-        self.fusion = fusion
-        self.fusion.prepare(self.device)
+        with torch.cuda.device(self.device):
+            if encoders is not None:
+                self.encoders = list(encoders)
+                for e in self.encoders:
+                    if e.device != self.device:
+                        raise ValueError(f"encoder {e.spec.name} lives on {e.device}, path on {self.device}")
+            else:
+                self.encoders = [HipEncoder(s, w, self.device) for s, w in zip(specs, enc_weights)]
+            self.out_size = out_size
+            self.set_parameters(proj_weights, fusion)
         self.tokens_out = {s.t_out * out_size * out_size for s in specs}
         if len(self.tokens_out) != 1:  # merv.py:175-193 consistency assert
             raise ValueError(f"Output token length is not consistent across projectors: {self.tokens_out}")
         self.T_vis = self.tokens_out.pop()
         self.concurrent = concurrent_streams and len(self.encoders) > 1
         self.streams = [torch.cuda.Stream(self.device) for _ in self.encoders]
-        self._bufs: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
+        self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
 
-    # -- buffers are persistent per (encoder, batch): no allocator traffic and no cross-stream lifetime issues
-    def _enc_bufs(self, i: int, B: int) -> Dict[str, torch.Tensor]:
-        key = (i, B)
+    def set_parameters(self, proj_weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                       fusion: Optional[CrossAttentionAdapterLearnableQuery]) -> None:
+        """(Re)take the trainable tail's parameters: bf16 device copies of the projector weights, fp32 biases, and the
+        fusion module's folded query vector. The frozen encoders and every buffer stay as they are."""
+        if fusion is None and len(self.encoders) != 1:
+            raise TypeError("argument of type 'NoneType' is not iterable")  # reference behaviour, merv.py:607 (App. B.4)
+        with torch.cuda.device(self.device):
+            old = getattr(self, "proj", None)
+            if old is not None and all(o[0].shape == w.shape for o, (w, _) in zip(old, proj_weights)):
+                for (ow, ob), (w, b) in zip(old, proj_weights):  # in place, ordered on the current stream behind the last
+                    ow.copy_(w.detach())                          # step's event join: no buffer a side stream reads is freed
+                    ob.copy_(b.detach())
+            else:
+                self.proj = [(w.detach().to(self.device, torch.bfloat16).contiguous(),
+                              b.detach().to(self.device, torch.float32).contiguous()) for w, b in proj_weights]
+            self.llm_dim = self.proj[0][0].shape[0]
+            self.fusion = fusion
+            if fusion is not None:
+                self.fusion.prepare(self.device)
+
+    # -- buffers are persistent per (encoder, batch, frames): no allocator traffic and no cross-stream lifetime issues
+    def _enc_bufs(self, i: int, B: int, frames: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        s = self.specs[i]
+        t_out = s.t_out if frames is None else frames // s.tubelet
+        key = (i, B, t_out)
         if key not in self._bufs:
-            s = self.specs[i]
             o = self.out_size
             self._bufs[key] = {
-                "tokens": torch.empty(B, s.num_patches, s.dim, dtype=torch.bfloat16, device=self.device),
-                "pooled": torch.empty(B * s.t_out * o * o, s.dim, dtype=torch.bfloat16, device=self.device),
-                "proj": torch.empty(B, self.T_vis, self.llm_dim, dtype=torch.bfloat16, device=self.device),
+                "tokens": torch.empty(B, t_out * s.s_out, s.dim, dtype=torch.bfloat16, device=self.device),
+                "pooled": torch.empty(B * t_out * o * o, s.dim, dtype=torch.bfloat16, device=self.device),
+                "proj": torch.empty(B, t_out * o * o, self.llm_dim, dtype=torch.bfloat16, device=self.device),
             }
             self.encoders[i].workspace(B)
         return self._bufs[key]
 
-    def encode_project(self, i: int, pixels: torch.Tensor, stream: torch.cuda.Stream,
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """a4-a9 for encoder i on `stream`: pixels -> projected [B, T_vis, llm] bf16."""
+    def buffers(self, i: int, B: int, frames: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Encoder i's persistent buffers for batch B: "tokens" [B, T*S, C] (a4-a8 output), "pooled", "proj" [B, T*64, llm]
+        (a9 output) -- what the last forward of that shape left there (inspection / parity checks)."""
+        return self._enc_bufs(i, B, frames)
+
+    def encode_project(self, i: int, pixels: torch.Tensor, stream: Optional[torch.cuda.Stream] = None,
+                       out: Optional[torch.Tensor] = None, frames: Optional[int] = None) -> torch.Tensor:
+        """a4-a9 for encoder i on `stream`: pixels -> projected [B, T_vis, llm] bf16. `frames` (per-frame encoders only):
+        the pixel tensor holds that many frames per video instead of the spec's count (a frame-range work unit of the
+        multi-GPU placement; LanguageBind in whole clips of 8): the result is the matching [B, frames/tubelet*64, llm] row
+        range of the full projection, bit for bit (frames are independent sequences and the pool does not cross frames)."""
         s = self.specs[i]
         B = pixels.shape[0]
-        bufs = self._enc_bufs(i, B)
-        tok = self.encoders[i].forward(pixels, out=bufs["tokens"], stream=stream)
-        dst = out if out is not None else bufs["proj"]
-        w, b = self.proj[i]
-        rc = self.lib.merv_projector_forward(ptr(tok), B, s.t_out, s.hp, s.dim, self.out_size, ptr(w), ptr(b),
-                                             self.llm_dim, ptr(bufs["pooled"]), ptr(dst), stream.cuda_stream)
-        check(rc, "merv_projector_forward")
+        if frames is not None and frames == s.frames:
+            frames = None
+        with torch.cuda.device(self.device):
+            if stream is None:
+                stream = torch.cuda.current_stream(self.device)
+            bufs = self._enc_bufs(i, B, frames)
+            tok = self.encoders[i].forward(pixels, out=bufs["tokens"], stream=stream, frames=frames)
+            dst = out if out is not None else bufs["proj"]
+            w, b = self.proj[i]
+            t_out = s.t_out if frames is None else frames // s.tubelet
+            rc = self.lib.merv_projector_forward(ptr(tok), B, t_out, s.hp, s.dim, self.out_size, ptr(w), ptr(b),
+                                                 self.llm_dim, ptr(bufs["pooled"]), ptr(dst), stream.cuda_stream)
+            check(rc, "merv_projector_forward")
         return dst
 
     def fuse(self, projected: Sequence[torch.Tensor]):
-        return self.fusion(list(projected))
+        """a10 on the current stream into persistent buffers. Returns (fused [B,T_vis,llm] bf16, weights [B,E] fp32)."""
+        if self.fusion is None:
+            return projected[0], None
+        B = projected[0].shape[0]
+        fb = self._fuse_bufs.get(B)
+        if fb is None:
+            E = len(projected)
+            fb = self._fuse_bufs[B] = {
+                "partial": torch.empty(self.lib.merv_fusion_workspace_floats(B, E, self.T_vis), dtype=torch.float32, device=self.device),
+                "weights": torch.empty(B, E, dtype=torch.float32, device=self.device),
+                "out": torch.empty(B, self.T_vis, self.llm_dim, dtype=torch.bfloat16, device=self.device),
+            }
+        with torch.cuda.device(self.device):
+            return self.fusion(list(projected), out=fb["out"], partial=fb["partial"], weights=fb["weights"])
 
-    def forward(self, pixels: Sequence[torch.Tensor]):
-        """pixels[i]: encoder i's post-transform tensor. Returns (fused [B,T_vis,llm] bf16, weights [B,E] fp32)."""
+    def _run_branches(self, pixels: Sequence[torch.Tensor], project: bool) -> List[torch.Tensor]:
+        """The E independent branches (merv.py:563-566), each on its own stream when `concurrent`, event-joined on the
+        current stream. project=True: a4-a9 (projected tokens); False: a4-a8 only (encoder tokens [B, T*S, C])."""
         if len(pixels) != len(self.encoders):
             raise ValueError(f"expected {len(self.encoders)} pixel tensors, got {len(pixels)}")
         main = torch.cuda.current_stream(self.device)
-        projected = []
+
+        def branch(i, pix, st):
+            if project:
+                return self.encode_project(i, pix, st)
+            bufs = self._enc_bufs(i, pix.shape[0])
+            return self.encoders[i].forward(pix, out=bufs["tokens"], stream=st)
+
+        outs = []
         if self.concurrent:
-            start = torch.cuda.Event()
+            if torch.cuda.is_current_stream_capturing():  # events recorded inside a capture belong to that graph
+                start, dones = torch.cuda.Event(), [torch.cuda.Event() for _ in pixels]
+            else:
+                if 0 not in self._events:
+                    self._events[0] = (torch.cuda.Event(), [torch.cuda.Event() for _ in pixels])
+                start, dones = self._events[0]
             start.record(main)
             for i, pix in enumerate(pixels):
                 st = self.streams[i]
                 st.wait_event(start)
-                projected.append(self.encode_project(i, pix, st))
-                done = torch.cuda.Event()
-                done.record(st)
-                main.wait_event(done)
+                outs.append(branch(i, pix, st))
+                dones[i].record(st)
+                main.wait_event(dones[i])
         else:
             for i, pix in enumerate(pixels):
-                projected.append(self.encode_project(i, pix, main))
-        return self.fuse(projected)
+                outs.append(branch(i, pix, main))
+        return outs
 
+    def encode_tokens(self, pixels: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+        """a4-a8: the encoders' patch tokens [B, T*S, C] bf16 (persistent buffers), for callers that differentiate the
+        projector / fusion themselves (merv_amd/train.py)."""
+        with torch.cuda.device(self.device):
+            return self._run_branches(pixels, project=False)
+
+    def forward(self, pixels: Sequence[torch.Tensor]):
+        """pixels[i]: encoder i's post-transform tensor. Returns (fused [B,T_vis,llm] bf16, weights [B,E] fp32 | None).
+        The returned tensors are the path's persistent buffers: the next forward of the same batch size overwrites them
+        (stream-ordered), so clone what must outlive it."""
+        with torch.cuda.device(self.device):
+            return self.fuse(self._run_branches(pixels, project=True))
 
     def capture(self, pixels: Sequence[torch.Tensor]):
         """Record one forward for these input shapes into a hipGraph (torch.cuda.CUDAGraph: the library's launches go
@@ -128,41 +215,90 @@ class MervVisualPath:
 # ------------------------------------------------------------------------------------------------------------
 # multi-GPU placement
 # ------------------------------------------------------------------------------------------------------------
-def plan_units(costs: Sequence[float], n_videos: int, world: int) -> List[List[Tuple[int, int, int]]]:
-    """Place (encoder e, video range [v0, v1)) work units on `world` ranks.
+def plan_units(costs: Sequence[float], n_videos: int, world: int, frames: Optional[Sequence[int]] = None,
+               atoms: Optional[Sequence[int]] = None) -> List[List[Tuple[int, int, int, int, int]]]:
+    """Place the visual path's independent work on `world` ranks. Returns, per rank, units (e, v0, v1, f0, f1): encoder e
+    on videos [v0, v1) and frames [f0, f1) of each (v1 - v0 > 1 only with whole videos).
 
-    costs[e] = FLOPs of encoder e per video. Units are whole (encoder, video) pairs; each rank receives, per
-    encoder, one contiguous run of videos so that it runs ONE batched forward per encoder. Greedy fill in
-    descending encoder cost: walk the ranks, give each the number of videos that brings it closest to the
-    per-rank target without splitting a video. Returns per rank a list of (e, v0, v1). Deterministic; every
-    (e, v) appears exactly once.
-    """
+    costs[e] = FLOPs of encoder e per video; frames[e] = frames per video; atoms[e] = the smallest frame count that is an
+    independent piece of work for encoder e: 1 for per-frame encoders (DINOv2, SigLIP: every frame is
+    its own sequence, dinov2_video.py:135-136), the temporal-attention clip length for LanguageBind (8: clips are independent
+    by construction, modeling_video.py:140-146), all frames for a joint space-time encoder (ViViT). Without frames / atoms
+    only whole videos are placed.
+
+    Method: the atoms are laid on a line ordered by (encoder cost descending, video, frame) and the line is cut into at most
+    `world` contiguous segments of minimal maximum cost (exact for this order: bisection on the bound + greedy fill), so a
+    rank holds, per encoder, ONE contiguous run of atoms = at most a partial leading video, a batch of whole videos and a
+    partial trailing video. With 8 videos per rank the imbalance is < 1 %; with ONE video on 4 / 8 ranks the makespan is
+    1.89 / 1.64 TFLOP against 3.28 for one-encoder-per-GPU. Deterministic; every (e, v, frame) appears exactly once."""
     E = len(costs)
-    total = sum(costs) * n_videos
-    target = total / world
-    load = [0.0] * world
-    plan: List[List[Tuple[int, int, int]]] = [[] for _ in range(world)]
+    frames = list(frames) if frames is not None else [1] * E
+    atoms = list(atoms) if atoms is not None else list(frames)
+    for e in range(E):
+        if atoms[e] <= 0 or frames[e] % atoms[e]:
+            raise ValueError(f"encoder {e}: atom of {atoms[e]} frames does not divide {frames[e]}")
     order = sorted(range(E), key=lambda e: -costs[e])
+    line: List[Tuple[int, int, int, float]] = []  # (e, v, atom index, cost)
     for e in order:
-        v = 0
-        # ranks sorted by current load (least loaded first), stable
-        ranks = sorted(range(world), key=lambda r: (load[r], r))
-        for j, r in enumerate(ranks):
-            if v >= n_videos:
-                break
-            remaining_ranks = len(ranks) - j
-            room = max(target - load[r], 0.0)
-            k = int(round(room / costs[e])) if costs[e] > 0 else n_videos - v
-            if remaining_ranks == 1:
-                k = n_videos - v
-            k = max(0, min(k, n_videos - v))
-            if k == 0:
-                continue
-            plan[r].append((e, v, v + k))
-            load[r] += k * costs[e]
-            v += k
-        if v < n_videos:  # rounding left a tail: give it to the least-loaded rank
-            r = min(range(world), key=lambda q: (load[q], q))
-            plan[r].append((e, v, n_videos))
-            load[r] += (n_videos - v) * costs[e]
+        per = frames[e] // atoms[e]
+        for v in range(n_videos):
+            for a in range(per):
+                line.append((e, v, a, costs[e] / per))
+    if not line:
+        return [[] for _ in range(world)]
+
+    def cut(bound: float) -> Optional[List[int]]:
+        """Greedy fill under `bound`: segment start indices, or None if more than `world` segments are needed."""
+        starts, load = [0], 0.0
+        for i, (_, _, _, c) in enumerate(line):
+            if load + c > bound * (1 + 1e-12) and load > 0.0:
+                starts.append(i)
+                load = 0.0
+                if len(starts) > world:
+                    return None
+            load += c
+        return starts
+
+    lo = max(max(c for *_, c in line), sum(c for *_, c in line) / world)
+    hi = sum(c for *_, c in line)
+    best = cut(hi)
+    if cut(lo) is not None:
+        best = cut(lo)
+    else:
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            got = cut(mid)
+            if got is None:
+                lo = mid
+            else:
+                hi, best = mid, got
+    bounds = best + [len(line)]
+    plan: List[List[Tuple[int, int, int, int, int]]] = [[] for _ in range(world)]
+    for r in range(len(best)):
+        seg = line[bounds[r]:bounds[r + 1]]
+        i = 0
+        while i < len(seg):  # group the segment's atoms of one encoder into (partial video | whole videos | partial video)
+            e, v, a, _ = seg[i]
+            per = frames[e] // atoms[e]
+            j = i
+            while j < len(seg) and seg[j][0] == e and seg[j][1] == v:
+                j += 1
+            if a == 0 and j - i == per:  # whole video: extend over following whole videos of the same encoder
+                v1 = v + 1
+                while j + per <= len(seg) and seg[j][0] == e and seg[j][1] == v1 and seg[j][2] == 0 and \
+                        seg[j + per - 1][0] == e and seg[j + per - 1][1] == v1:
+                    j += per
+                    v1 += 1
+                plan[r].append((e, v, v1, 0, frames[e]))
+            else:
+                plan[r].append((e, v, v + 1, a * atoms[e], (a + (j - i)) * atoms[e]))
+            i = j
+    return plan
+
+
+def plan_one_encoder_per_rank(n_encoders: int, n_videos: int, world: int, frames: Sequence[int]):
+    """The literal BASELINE.json configs[2] placement: encoder e runs on rank e % world for every video."""
+    plan: List[List[Tuple[int, int, int, int, int]]] = [[] for _ in range(world)]
+    for e in range(n_encoders):
+        plan[e % world].append((e, 0, n_videos, 0, frames[e]))
     return plan

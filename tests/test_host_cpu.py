@@ -91,28 +91,39 @@ def test_create_rejects_bad_descriptor():
 
 
 def test_plan_units_properties():
+    from merv_amd.distributed import atom_frames
     from merv_amd.encoder import merv_full_specs
-    from merv_amd.visual_path import plan_units
-    costs = [s.flops_per_video() for s in merv_full_specs()]
+    from merv_amd.visual_path import plan_one_encoder_per_rank, plan_units
+    specs = merv_full_specs()
+    costs = [s.flops_per_video() for s in specs]
+    frames = [s.frames for s in specs]
+    atoms = [atom_frames(s) for s in specs]
+    assert atoms == [8, 1, 32, 1]  # LanguageBind clips, DINOv2 frames, ViViT whole, SigLIP frames
     for world in (1, 2, 4, 8):
         for per in (1, 2, 8):
             Gv = world * per
-            plan = plan_units(costs, Gv, world)
+            plan = plan_units(costs, Gv, world, frames, atoms)
             seen = set()
-            for r, units in enumerate(plan):
-                for (e, v0, v1) in units:
-                    assert 0 <= v0 < v1 <= Gv
+            for units in plan:
+                for (e, v0, v1, f0, f1) in units:
+                    assert 0 <= v0 < v1 <= Gv and 0 <= f0 < f1 <= frames[e] and f0 % atoms[e] == 0 and f1 % atoms[e] == 0
                     for v in range(v0, v1):
-                        assert (e, v) not in seen
-                        seen.add((e, v))
-                assert len({e for (e, _, _) in units}) == len(units)  # one run per encoder per rank
-            assert len(seen) == 4 * Gv
-            load = [sum(costs[e] * (v1 - v0) for (e, v0, v1) in u) for u in plan]
+                        for f in range(f0, f1):
+                            assert (e, v, f) not in seen
+                            seen.add((e, v, f))
+            assert len(seen) == Gv * sum(frames)
+            load = [sum(costs[e] * (v1 - v0) * (f1 - f0) / frames[e] for (e, v0, v1, f0, f1) in u) for u in plan]
             if per >= 8:
-                assert max(load) / (sum(load) / world) < 1.12, (world, per, load)
-    # north_star's literal placement: 4 GPUs, 1 video -> one encoder per GPU
-    p = plan_units(costs, 1, 4)
-    assert sorted(u[0][0] for u in p) == [0, 1, 2, 3] and all(len(u) == 1 for u in p)
+                assert max(load) / (sum(load) / world) < 1.02, (world, per, load)
+    # whole videos only (no atoms given): units never split a video
+    for units in plan_units(costs, 5, 2):
+        assert all((f0, f1) == (0, 1) for (_, _, _, f0, f1) in units)
+    # north_star's literal placement: 4 GPUs -> one encoder per GPU; the balanced plan of the same case splits DINOv2 by frames
+    p = plan_one_encoder_per_rank(4, 1, 4, frames)
+    assert [u[0][0] for u in p] == [0, 1, 2, 3] and all(len(u) == 1 for u in p)
+    bal = plan_units(costs, 1, 4, frames, atoms)
+    assert any(e == 1 and (f0, f1) != (0, 16) for units in bal for (e, _, _, f0, f1) in units)
+    assert not any(e == 2 and (f0, f1) != (0, 32) for units in bal for (e, _, _, f0, f1) in units)  # ViViT never splits
 
 
 def test_registry_keys_and_unwired_variants():
