@@ -17,6 +17,25 @@
 #include "kernels.h"
 #include "prof.h"
 
+// Diagnostic builds only (tools/probes/attn_stamps.hip defines MERV_ATTN_STAMPS before including this file): s_memtime
+// stamps per wave into a buffer of their own. The product build compiles none of it.
+#ifdef MERV_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;  // [block][wave][32]
+#define MERV_STAMP(k)                                                                                       \
+    do {                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        unsigned long long t__;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        if (g_attn_stamps && (threadIdx.x & 63) == 0 && (k) < 32) {                                         \
+            const int blk__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);               \
+            g_attn_stamps[((size_t)blk__ * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32 + (k)] = t__;      \
+        }                                                                                                   \
+    } while (0)
+#else
+#define MERV_STAMP(k) do { } while (0)
+#endif
+
 namespace merv {
 namespace {
 
@@ -109,6 +128,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     const bf16_t* vbase = base + 2 * D + head * HD;
 
     const int q_base = (blockIdx.x * NW + wave) * (QPW * 32);  // first query row of this wave
+    MERV_STAMP(0);
 
     // Q^T B-operand fragments: element j of step s = Q[q][16 s + 8 h + j]
     bf16x8 qf[QPW][4];
@@ -182,11 +202,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 
     const int ntiles = (L + 63) / 64;
     load_tile(0);
+    MERV_STAMP(1);
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
         __syncthreads();  // previous tile's LDS reads are done
+        MERV_STAMP(2 + 4 * t);
         write_tile();
+        MERV_STAMP(3 + 4 * t);
         __syncthreads();
+        MERV_STAMP(4 + 4 * t);
         if (t + 1 < ntiles) load_tile(kv0 + 64);
         const bool tail = kv0 + 64 > L;
         // 257 = 4 * 64 + 1 and 3137 = 49 * 64 + 1: in the last tile of those sequences keys 32..63 are all padding;
@@ -278,7 +302,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 }
             }
         }
+        MERV_STAMP(5 + 4 * t);
     }
+    MERV_STAMP(30);
 
     // ---- output: transpose each 32 x 64 tile through LDS so the global stores are 16 B per lane, 128 B per row ----
     __syncthreads();  // every wave is done with the K/V tiles
@@ -320,6 +346,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads returned before the next tile overwrites
     }
+    MERV_STAMP(31);
 }
 
 // ---------------------------------------------------------------------------------------------------------
