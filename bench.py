@@ -43,7 +43,7 @@ TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance (DESIGN.md se
 PMC_TRAFFIC_FILE = "profiles/r02_pmc_gemm_traffic.json"
 
 
-def build_models(device, concurrent=True, want_ref=False):
+def build_models(device, concurrent=True, want_ref=False, ln_fold=True):
     """The merv-full visual stack with seeded random-init weights of the named architectures, generated on the GPU (there
     are no checkpoints here). GEMM weights are bf16-representable (the reference's parameters after
     `vidlm.to(torch.bfloat16)`, scripts/quick_start.py:12), so the CPU copy handed to the oracle (`want_ref`) holds
@@ -56,7 +56,8 @@ def build_models(device, concurrent=True, want_ref=False):
     bbs, ref_enc = [], []
     for i, (spec, bid, nf) in enumerate(zip(specs, BACKBONE_IDS, NUM_FRAMES)):
         w = random_weights(spec, 1000 + i, device=device, bf16_exact=True)
-        bb = VIDEO_BACKBONES[bid]["cls"](bid, "resize-naive", num_frames=nf, weights=w, device=device, **VIDEO_BACKBONES[bid]["kwargs"])
+        bb = VIDEO_BACKBONES[bid]["cls"](bid, "resize-naive", num_frames=nf, weights=w, device=device, ln_fold=ln_fold,
+                                         **VIDEO_BACKBONES[bid]["kwargs"])
         assert bb.spec == spec, (bb.spec, spec)
         bbs.append(bb)
         if want_ref:
@@ -189,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle run (parity + cpu_baseline)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the e2e generate() leg")
     ap.add_argument("--no-multi", action="store_true", help="N > 1: skip the extra unit-placement timings")
+    ap.add_argument("--no-ln-fold", action="store_true",
+                    help="separate LayerNorm kernels instead of the default folded form (A/B of the fold; same tolerance)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a hipGraph (single GPU; useful at --batch 1)")
     ap.add_argument("--mxfp8", action="store_true",
                     help="BASELINE.json configs[4] variant: block GEMMs on MXFP8 operands (NOT the headline bf16 metric; "
@@ -226,7 +229,7 @@ def main():
         lib.merv_debug_set_gemm_variant(int(os.environ["MERV_GEMM_GROUP_M"]) << 8)
     single = world == 1 and not force_dist
     want_ref = single and rank == 0 and not args.no_cpu_baseline and not args.mxfp8
-    specs, bbs, path, extras = build_models(device, concurrent=not args.sequential, want_ref=want_ref)
+    specs, bbs, path, extras = build_models(device, concurrent=not args.sequential, want_ref=want_ref, ln_fold=not args.no_ln_fold)
     if args.mxfp8:
         for enc in path.encoders:
             enc.enable_mxfp8()
@@ -365,6 +368,7 @@ def main():
                                     "(BASELINE.json configs[1])"),
                        "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
                        "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if replay is not None else ""),
+                       "layernorm": "separate kernels" if args.no_ln_fold else "LN1 / LN2 folded into qkv / fc1, statistics from the producing GEMM's epilogue",
                        "parallelism": ("single GPU" if single else
                                        f"(encoder, video, frame-range) units over {world} GPUs, RCCL {args.exchange} before fusion" if headline_units else
                                        f"data-parallel over videos on {world} GPUs, no data-path collective"),

@@ -43,7 +43,7 @@ class VideoBackbone(nn.Module):
         raise NotImplementedError("encoders are frozen and forward-only on the HIP path (merv.py:315-384)")
 
     # -- shared plumbing -------------------------------------------------------------------------------------
-    def _build(self, spec: EncoderSpec, weights, device, ingest: Callable) -> None:
+    def _build(self, spec: EncoderSpec, weights, device, ingest: Callable, ln_fold: bool = True) -> None:
         self.spec = spec
         if weights is None:
             raise ValueError(f"{type(self).__name__}: pass weights=<state dict> or weights='random' (no hub access here)")
@@ -53,7 +53,7 @@ class VideoBackbone(nn.Module):
             canon = weights
         else:
             canon = ingest(weights)
-        self.featurizer = HipEncoder(spec, canon, device)
+        self.featurizer = HipEncoder(spec, canon, device, ln_fold=ln_fold)
         # the reference's per-encoder CPU transform (row a3), as HIP kernels: uint8 [F,3,H,W] -> this encoder's layout
         from .preprocess import transform_for
         self.video_transform = transform_for(spec.name, torch.float32)
@@ -138,7 +138,7 @@ class LangBindVideoBackbone(VideoBackbone):
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
                  num_frames: int = 8, token: Optional[str] = None, weights=None, device="cuda:0",
-                 hidden_act: str = "gelu_erf", layers: int = 23) -> None:
+                 hidden_act: str = "gelu_erf", layers: int = 23, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
         assert "languagebind-video" in video_backbone_id, video_backbone_id
         assert image_resize_strategy == "resize-naive"  # languagebind/__init__.py:64
@@ -147,7 +147,7 @@ class LangBindVideoBackbone(VideoBackbone):
         self.token = token
         spec = EncoderSpec("languagebind", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BCFHW", 1, False,
                            True, False, False, 8, hidden_act, 1e-5)
-        self._build(spec, weights, device, lambda sd: W.from_languagebind_vision(sd, n_layers=layers))
+        self._build(spec, weights, device, lambda sd: W.from_languagebind_vision(sd, n_layers=layers), ln_fold)
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:
@@ -158,14 +158,14 @@ class DinoV2VideoBackbone(VideoBackbone):
     """dinov2_video.py:27-179 -- timm vit_large_patch14_reg4_dinov2, get_intermediate_layers(n={L-2})."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
-                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 23) -> None:
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 23, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
         if "all-tokens" not in video_backbone_id:
             raise NotImplementedError(f"`{video_backbone_id}`: only the all-tokens selection is wired on the HIP path")
         spec = EncoderSpec("dinov2", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BFCHW", 5, False, False,
                            False, True, 0, "gelu_erf", 1e-6)
         self._build(spec, weights, device,
-                    lambda sd: W.from_timm_vit(sd, n_layers=layers, grid=default_image_size // 14))
+                    lambda sd: W.from_timm_vit(sd, n_layers=layers, grid=default_image_size // 14), ln_fold)
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:
@@ -176,14 +176,14 @@ class ViVITVideoBackbone(VideoBackbone):
     """vivit.py:24-155 -- HF VivitModel (google/vivit-b-16x2-kinetics400), last_hidden_state[:, 1:]."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
-                 num_frames: int = 32, weights=None, device="cuda:0", layers: int = 12) -> None:
+                 num_frames: int = 32, weights=None, device="cuda:0", layers: int = 12, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
         if "all-no-cls-16frames" not in video_backbone_id:
             raise NotImplementedError(f"`{video_backbone_id}`: only all-no-cls-16frames is wired on the HIP path")
         self.video_backbone_id = video_backbone_id
         spec = EncoderSpec("vivit", 768, 12, 3072, layers, 16, 2, default_image_size, num_frames, "BFCHW", 1, True, False, True,
                            False, 0, "gelu_tanh", 1e-6)
-        self._build(spec, weights, device, lambda sd: W.from_hf_vivit(sd, n_layers=layers))
+        self._build(spec, weights, device, lambda sd: W.from_hf_vivit(sd, n_layers=layers), ln_fold)
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:
@@ -194,13 +194,13 @@ class SiglipVideoBackbone(VideoBackbone):
     """siglip.py:35-174 -- timm vit_base_patch16_siglip_224, get_intermediate_layers(n={L-2}), no class token."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
-                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 11) -> None:
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 11, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
         if "siglip-vit-b16-224px-all" not in video_backbone_id:
             raise NotImplementedError(f"`{video_backbone_id}`: only the B/16-224 all-token selections are wired")
         spec = EncoderSpec("siglip", 768, 12, 3072, layers, 16, 1, default_image_size, num_frames, "BFCHW", 0, False, False,
                            False, False, 0, "gelu_erf", 1e-6)
-        self._build(spec, weights, device, lambda sd: W.from_timm_vit(sd, n_layers=layers))
+        self._build(spec, weights, device, lambda sd: W.from_timm_vit(sd, n_layers=layers), ln_fold)
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:

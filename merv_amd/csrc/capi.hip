@@ -1,6 +1,7 @@
 // C-ABI of libmerv_hip.so (see include/merv_hip.h): argument checking, encoder orchestration (a stream-ordered
 // sequence of kernel launches per encoder, no allocation, no synchronisation) and thin kernel wrappers.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -155,6 +156,7 @@ struct Workspace {
     uint8_t *aq, *asc;  // MXFP8 mode: quantised [M, dim] GEMM input (LayerNorm / attention output) and its block scales
     uint8_t *hq, *hsc;  // MXFP8 mode: quantised [M, mlp_dim] MLP hidden activations, written by fc1's epilogue
     float* stats;       // folded LayerNorm: {rstd, -mean * rstd} per row
+    float* parts;       // folded LayerNorm: per-row {sum, M2} partials per 64 columns, written by the producing GEMM's epilogue
     size_t total;
 };
 Workspace carve(const merv_encoder* e, int nseq, char* base) {
@@ -181,6 +183,7 @@ Workspace carve(const merv_encoder* e, int nseq, char* base) {
         w.hsc = (uint8_t*)take(mx_scale_bytes((int)M, e->d.mlp_dim));
     }
     w.stats = e->fold ? (float*)take(M * 2 * sizeof(float)) : nullptr;
+    w.parts = e->fold ? (float*)take(M * (D / 64) * 2 * sizeof(float)) : nullptr;
     w.total = off;
     return w;
 }
@@ -356,6 +359,22 @@ extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pi
         return launch_gemm_mx(g, s);
     };
 
+    // Folded LayerNorm statistics of the residual stream. The GEMM that last wrote ws.x (t_proj / proj / fc2) leaves per-row
+    // partials in ws.parts from its epilogue (GemmArgs::stats_out); a one-thread-per-row kernel combines them. Only when x
+    // was written by something else (the embedding, an in-place temporal-embedding add) is the stream re-read.
+    bool parts_valid = false;
+    auto ln_stats = [&]() -> hipError_t {
+        if (parts_valid) {
+            StatsFinalizeArgs fa{ws.parts, ws.stats, M, D / 64, d.ln_eps};
+            return launch_stats_finalize(fa, s);
+        }
+        RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
+        return launch_row_stats(rs, s);
+    };
+    // does a folded LayerNorm read x right after the GEMM that writes it here? (then that GEMM produces the partials)
+    static const bool fused_stats = !(getenv("MERV_LN_FUSED_STATS") && getenv("MERV_LN_FUSED_STATS")[0] == '0');  // A/B hook
+    const bool fold_qkv = e->fold && !mx_qkv && fused_stats, fold_fc1 = e->fold && !mx_fc1 && fused_stats;
+
     // ---- transformer blocks ----
     for (int li = 0; li < d.layers; ++li) {
         const merv_layer_weights& L = e->layers[li];
@@ -372,15 +391,16 @@ extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pi
             MERV_HIP(launch_temporal_attention(ta, s));
             GemmArgs o = gemm_args(ws.y, D, L.t_proj_w, D, ws.x, D, M, D, L.t_proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D;
+            if (fold_qkv) o.stats_out = ws.parts;  // LN1 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
             else MERV_HIP(launch_gemm(o, s));
+            parts_valid = fold_qkv;
         }
         {
-            const bool folded = e->fold && !mx_qkv;  // statistics only; the normalisation is algebra in the GEMM epilogue
+            const bool folded = e->fold && !mx_qkv;  // no LayerNorm pass; the normalisation is algebra in the GEMM epilogue
             GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
             if (folded) {
-                RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
-                MERV_HIP(launch_row_stats(rs, s));
+                MERV_HIP(ln_stats());
                 q.A = ws.x; q.W = e->fl[li].qkv_w; q.bias = e->fl[li].qkv_db;
                 q.row_stats = ws.stats; q.ln_colsum = e->fl[li].qkv_cs;
             } else {
@@ -395,15 +415,16 @@ extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pi
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
+            if (fold_fc1) o.stats_out = ws.parts;  // LN2 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
             else MERV_HIP(launch_gemm(o, s));
+            parts_valid = fold_fc1;
         }
         {
             const bool folded = e->fold && !mx_fc1;
             GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
             if (folded) {
-                RowStatsArgs rs{ws.x, ws.stats, M, D, d.ln_eps};
-                MERV_HIP(launch_row_stats(rs, s));
+                MERV_HIP(ln_stats());
                 f1.A = ws.x; f1.W = e->fl[li].fc1_w; f1.bias = e->fl[li].fc1_db;
                 f1.row_stats = ws.stats; f1.ln_colsum = e->fl[li].fc1_cs;
             } else {
@@ -416,8 +437,13 @@ extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pi
             else MERV_HIP(launch_gemm(f1, s));
             GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
+            // the next reader of x is the following block's LN1 -- unless that block starts with the temporal sub-block
+            // (its LayerNorm kernel first adds the temporal embedding into x) or this was the last block
+            const bool next_ln1 = fold_qkv && d.temporal_frames == 0 && li + 1 < d.layers;
+            if (next_ln1) f2.stats_out = ws.parts;
             if (mx_fc2) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
             else MERV_HIP(launch_gemm(f2, s));
+            parts_valid = next_ln1;
         }
     }
 

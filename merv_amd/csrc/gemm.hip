@@ -48,6 +48,15 @@ MERV_DEVICE void dma_rows8(const bf16_t* __restrict__ g, int ld, int row0, int r
                                      (__attribute__((address_space(3))) void*)(lds_tile + rowblk * 1024), 16, 0, 0);
 }
 
+// Sum over each aligned group of 8 lanes, result in all 8: three DPP adds (quad_perm xor 1, xor 2, row_half_mirror), no LDS
+// crossbar (__shfl_xor lowers to ds_bpermute here: ~100 cycles each, 6 per row chunk).
+MERV_DEVICE float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // lanes ^1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // lanes ^2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // lane i <-> 7 - i
+    return v;
+}
+
 // ---- epilogue (shared by all tile configurations) ----
 template <int WTM_FULL, int WTN, bool REMAP, int ACT, int MSPLIT = 1>
 MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FULL / 16], char* smem, int wave, int lane, int m0,
@@ -86,6 +95,24 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
 #pragma unroll
         for (int i = 0; i < NI; ++i) ls4[i] = float4{1.f, 1.f, 1.f, 1.f};
     }
+    // folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]. Row statistics (the row of acc[i][j] is j * 16 + frow of its
+    // part) and column sums are requested HERE, ahead of the staging barrier and the residual loads, so their latency is hidden
+    // (loaded at first use they stalled every part of every tile for a full global-load round trip: +3 % on qkv / fc1 launches)
+    float2 rs_all[MSPLIT][MI];
+    float4 cs4[NI];
+    if (p.row_stats) {
+        const int efrow = elane & 15;
+#pragma unroll
+        for (int part = 0; part < MSPLIT; ++part)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+                int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + efrow;
+                m = m < p.M ? m : p.M - 1;
+                rs_all[part][j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
+            }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cs4[i] = *(const float4*)(p.ln_colsum + wn0 + i * 16 + (elane >> 4) * 4);
+    }
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
@@ -119,28 +146,18 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
         if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]; the row of acc[i][j] is j * 16 + frow of this part
-        float2 rs[MI];
-        if (p.row_stats) {
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
-                m = m < p.M ? m : p.M - 1;
-                rs[j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
-            }
-        }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            float4 cs = float4{0.f, 0.f, 0.f, 0.f};
-            if (p.row_stats) cs = *(const float4*)(p.ln_colsum + wn0 + i * 16 + fq * 4);  // loaded here: keeps it out of the K-loop's registers
+            const float4 cs = cs4[i];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
                 f32x4 v = acc[i][part * MI + j];
                 if (p.row_stats) {
-                    v[0] = fmaf(v[0], rs[j].x, rs[j].y * cs.x);
-                    v[1] = fmaf(v[1], rs[j].x, rs[j].y * cs.y);
-                    v[2] = fmaf(v[2], rs[j].x, rs[j].y * cs.z);
-                    v[3] = fmaf(v[3], rs[j].x, rs[j].y * cs.w);
+                    const float2 rs = rs_all[part][j];
+                    v[0] = fmaf(v[0], rs.x, rs.y * cs.x);
+                    v[1] = fmaf(v[1], rs.x, rs.y * cs.y);
+                    v[2] = fmaf(v[2], rs.x, rs.y * cs.z);
+                    v[3] = fmaf(v[3], rs.x, rs.y * cs.w);
                 }
                 const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
                 const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
@@ -162,6 +179,20 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
+            }
+            if (p.stats_out) {  // uniform: {sum, M2} of this row's 64 columns (the 8 lanes ec = 0..7 hold 8 values each)
+                float f[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { f[2 * q] = bflo(t[q]); f[2 * q + 1] = bfhi(t[q]); }
+                const float sm = sum8_dpp(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
+                const float mu = sm * (1.f / 64.f);
+                float m2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float d = f[q] - mu; m2 = fmaf(d, d, m2); }
+                m2 = sum8_dpp(m2);
+                const int m = m0 + wr * WTM_FULL + part * WTM + (elane >> 3) + 8 * it;
+                if (valid[it] && ec == 0)
+                    *(float2*)(p.stats_out + 2 * ((size_t)m * (p.N >> 6) + (wn0 >> 6))) = float2{sm, m2};
             }
             if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (4 lanes = one 32-column block of the row)
                 float r[8];
@@ -809,6 +840,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     rest.C = a.C + (size_t)rows1 * a.ldc;
     if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
     if (a.row_stats) rest.row_stats = a.row_stats + 2 * (size_t)rows1;
+    if (a.stats_out) rest.stats_out = a.stats_out + 2 * (size_t)rows1 * (a.N >> 6);
     if (a.mx_out_q) {  // rows1 is a multiple of 256: whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
         rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;
         rest.mx_out_scales = a.mx_out_scales + (size_t)(rows1 / 64) * 256;

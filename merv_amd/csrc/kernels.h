@@ -28,6 +28,12 @@ struct GemmArgs {
     // ln_colsum[n] = sum_k W'[n][k]; bias then holds W.beta + the layer's bias (all prepared once by launch_ln_fold)
     const float* row_stats;   // [M][2] or nullptr
     const float* ln_colsum;   // [N]
+    // any launch whose output C is the residual stream a folded LayerNorm will read next: when stats_out is set the epilogue
+    // also writes, per output row and per 64-column wave tile, {sum, M2 = sum of squared deviations from the tile's own mean}
+    // of the bf16-ROUNDED values it stores: stats_out[(m * (N / 64) + n / 64) * 2 .. +1]. launch_stats_finalize combines the
+    // N / 64 partials of a row (Chan's parallel variance: exact, no E[x^2] - mean^2 cancellation) into row_stats for the
+    // consuming GEMM, so no kernel re-reads the residual stream for LayerNorm.
+    float* stats_out;
     // any launch: when mx_out_q is set the epilogue writes its (bf16-rounded) result as MXFP8 -- e4m3 [M, N] + block
     // scales in the layout of mx_quantize -- instead of bf16 C (the next GEMM's quantised input, e.g. fc1 -> fc2)
     uint8_t* mx_out_q;
@@ -80,6 +86,15 @@ struct RowStatsArgs {
     float eps;
 };
 hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s);
+
+// Combine the per-64-column partials a producer GEMM's epilogue wrote (GemmArgs::stats_out) into stats[m] = {rstd, -mean * rstd}.
+struct StatsFinalizeArgs {
+    const float* parts;  // [M][nparts][2] = {sum, M2} over 64 columns each
+    float* stats;        // [M][2]
+    int M, nparts;       // D = 64 * nparts
+    float eps;
+};
+hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s);
 
 // One-time fold of a LayerNorm into the Linear that consumes it: wf[n][k] = bf16(w[n][k] * gamma[k]),
 // colsum[n] = sum_k wf[n][k] (of the ROUNDED values, so the algebra stays exact), dbias[n] = sum_k w[n][k] * beta[k] + bias[n].

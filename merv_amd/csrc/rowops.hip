@@ -368,6 +368,32 @@ hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// One thread per row: Chan et al.'s pairwise combination of (n, mean, M2) over the row's 64-column partials.
+__global__ __launch_bounds__(256) void stats_finalize_kernel(StatsFinalizeArgs p) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= p.M) return;
+    const float2* pr = (const float2*)p.parts + (size_t)row * p.nparts;
+    float tot = 0.f;
+    for (int i = 0; i < p.nparts; ++i) tot += pr[i].x;
+    const float D = 64.f * (float)p.nparts;
+    const float mean = tot / D;
+    float m2 = 0.f;
+    for (int i = 0; i < p.nparts; ++i) {
+        const float2 v = pr[i];  // second read: L1 / L2 resident (128 B per row)
+        const float d = v.x * (1.f / 64.f) - mean;
+        m2 += v.y + 64.f * d * d;
+    }
+    const float rstd = rsqrtf(m2 / D + p.eps);
+    *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
+}
+
+hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.nparts <= 0 || !a.parts || !a.stats) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.D % 8 != 0 || a.D > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;

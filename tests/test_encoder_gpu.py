@@ -83,8 +83,9 @@ def test_projector_vs_oracle(dev):
 
 @pytest.mark.parametrize("name", ["languagebind", "dinov2", "vivit", "siglip"])
 def test_ln_fold_matches_oracle_and_plain_path(dev, name):
-    """LayerNorm folded into qkv / fc1 (exact algebra, different rounding points): same tolerance against the oracle as
-    the plain path, and the two HIP paths agree with each other to bf16 noise. LayerNorm weights are drawn away from
+    """LayerNorm folded into qkv / fc1 (exact algebra, different rounding points; the default) with its row statistics
+    taken from the producing GEMM's epilogue (per-64-column {sum, M2} partials + Chan combine): same tolerance against the
+    oracle as the separate-LayerNorm path, and the two HIP paths agree with each other to bf16 noise. LayerNorm weights are drawn away from
     (1, 0) and the input is given a per-row offset so that gamma, beta and the mean term all matter."""
     import dataclasses
     from oracle import merv_oracle as O
@@ -103,8 +104,10 @@ def test_ln_fold_matches_oracle_and_plain_path(dev, name):
     pix = torch.randn(spec.pixel_shape(1), generator=g)
     cfg = O.EncoderCfg(**{k: getattr(spec, k) for k in O.EncoderCfg.__dataclass_fields__})
     ref = O.encoder_forward(pix, cfg, W)
-    plain = HipEncoder(spec, W, dev).forward(pix.to(dev)).float().cpu()
-    folded = HipEncoder(spec, W, dev).enable_ln_fold().forward(pix.to(dev)).float().cpu()
+    plain = HipEncoder(spec, W, dev, ln_fold=False).forward(pix.to(dev)).float().cpu()
+    enc_f = HipEncoder(spec, W, dev)  # folded is the default
+    assert enc_f.ln_fold
+    folded = enc_f.forward(pix.to(dev)).float().cpu()
     assert rel_l2(plain, ref) < 2e-2
     assert rel_l2(folded, ref) < 2e-2
     assert rel_l2(folded, plain) < 1.5e-2
@@ -122,7 +125,7 @@ def test_ln_fold_at_split_gemm_sizes(dev):
     W["layers"][0]["ln1_w"] = 1.0 + 0.5 * torch.randn(spec.dim, generator=g)
     W["layers"][0]["ln2_b"] = 0.5 * torch.randn(spec.dim, generator=g)
     pix = torch.randn(spec.pixel_shape(8), generator=g).to(torch.bfloat16).to(dev)
-    plain = HipEncoder(spec, W, dev).forward(pix).float()
-    folded = HipEncoder(spec, W, dev).enable_ln_fold().forward(pix).float()
+    plain = HipEncoder(spec, W, dev, ln_fold=False).forward(pix).float()
+    folded = HipEncoder(spec, W, dev).forward(pix).float()
     per_video = ((folded - plain).flatten(1).norm(dim=1) / plain.flatten(1).norm(dim=1)).cpu()
     assert float(per_video.max()) < 1.5e-2, per_video  # the last video's rows are the ones behind the split

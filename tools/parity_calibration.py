@@ -6,7 +6,8 @@ One video, full depth (23 / 23 / 12 / 11 consumed blocks), full width, ONE set o
   hip      -- the product: libmerv_hip.so through MervVisualPath;
   refstack -- the reference's own stack on this GPU: plain PyTorch-ROCm bf16 ops (library GEMM, SDPA, layer_norm, gelu), what
               timm / transformers launch under vidlm.to(bf16) + autocast (tools/torch_rocm_baseline.py).
-and, with --ln-fold, the HIP path with LayerNorm folded into the qkv / fc1 GEMMs.
+(here built with separate LayerNorm kernels) and, with --ln-fold, the HIP path with LayerNorm folded into the qkv / fc1
+GEMMs -- the product default.
 Reports err(refstack vs oracle), err(hip vs oracle), err(hip vs refstack) per encoder, per projector and on the fused
 [1,1024,4096] tokens. Prints one JSON object (commit it as profiles/rNN_parity_calibration.json)."""
 import json
@@ -26,7 +27,7 @@ from torch_rocm_baseline import path_bf16, to_ref_stack
 def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    specs, _, path, extras = bench.build_models(dev, concurrent=False, want_ref=True)
+    specs, _, path, extras = bench.build_models(dev, concurrent=False, want_ref=True, ln_fold=False)
     ref = extras["ref"]
     pix = bench.synth_pixels(specs, 1, dev, seed=4242)
 
