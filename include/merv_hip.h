@@ -268,6 +268,12 @@ void merv_debug_set_gemm_variant(int32_t variant);
 /* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */
 int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t M, int32_t N, int32_t K, void *q_out,
                            void *scales_out, void *stream);
+/* test hook: the bf16 GEMM with the LayerNorm-partials output the encoder requests from the GEMMs that write its residual
+ * stream: per row, per 64 output columns, {sum, M2 about the 64-column mean} of the bf16-rounded values stored
+ * ([M][N/64][2] floats), which a one-thread-per-row kernel combines (Chan) into the statistics of a LayerNorm folded into
+ * the next GEMM. */
+int merv_debug_gemm_stats(const void *A, const void *W, void *C, const float *bias, const float *lscale, const void *res,
+                          int32_t M, int32_t N, int32_t K, int32_t act, float *stats_out, void *stream);
 
 /*
  * Per-launch HIP-event timing (bench.py roofline leg). class bits: 0 GEMM, 1 attention, 2 temporal attention,

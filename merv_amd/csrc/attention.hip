@@ -103,7 +103,14 @@ MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u3
 // NW waves per block, each wave owns QPW consecutive 32-row query tiles: one block covers NW*QPW*32 queries of one
 // (sequence, head) and streams the K/V tiles ONCE for all of them (L = 257/261 -> 3 waves x 3 tiles = 288 rows, one
 // block per (sequence, head); L = 196 -> 4 x 2; L = 3137 -> 13 blocks of 4 x 2).
-template <bool VTR, int NW, int QPW>
+// XQ = true (sequences of NW*QPW*32 + 1..8 tokens: 257 = 8 * 32 + 1, 261 = 8 * 32 + 5): the few query rows past the last full
+// tile do not get a padded 32-row tile of their own wave (a ninth tile on a 3 x 3 block: three waves on four SIMDs, no second
+// score set) -- the block stays 4 waves x 2 tiles, and the extra rows' attention is split over the waves BY KEY TILE: wave
+// t % NW multiplies them against key tile t right after its own two tiles (K / V of that tile are in LDS anyway), leaves
+// {partial O, max, sum} in LDS, and the partials are merged after the loop (flash-decoding style). Bit pattern of the
+// result differs from the single-pass order only by fp32 summation order.
+constexpr int XQ_ROWS = 8, XQ_SLOTS = 5;
+template <bool VTR, int NW, int QPW, bool XQ = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     constexpr int NT = NW * 64;
     constexpr int V_BYTES = VTR ? 64 * VROW_TR : 64 * VT_ROW;
@@ -111,10 +118,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     constexpr int KSTG = (512 + NT - 1) / NT;   // 16-byte chunks of a 64x64 bf16 tile per thread
     constexpr int PSTG = (256 + NT - 1) / NT;   // (key pair, chunk) items per thread for the transposing V path
     constexpr int OUT_BYTES = NW * 32 * 128;    // output staging (reuses the K/V region after the last tile)
-    constexpr int LDS_BYTES = (64 * KROW + V_BYTES) > OUT_BYTES ? (64 * KROW + V_BYTES) : OUT_BYTES;
+    constexpr int KV_BYTES = (64 * KROW + V_BYTES) > OUT_BYTES ? (64 * KROW + V_BYTES) : OUT_BYTES;
+    constexpr int XQ_BYTES = XQ ? XQ_SLOTS * XQ_ROWS * (HD + 4) * 4 : 0;  // per (slot, row): 64 partial outputs, max, two half sums
+    constexpr int LDS_BYTES = KV_BYTES + XQ_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* k_lds = smem;
     char* v_lds = smem + 64 * KROW;
+    float* xq_lds = (float*)(smem + KV_BYTES);  // [slot][row][HD + 4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,6 +149,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s)
             qf[qi][s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+    }
+
+    constexpr int XQ0 = NW * QPW * 32;  // first extra query row (XQ launches have one block per (sequence, head))
+    bf16x8 qx[4];
+    if constexpr (XQ) {
+        const int q_ld = XQ0 + r < L ? XQ0 + r : L - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qx[s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
     }
 
     f32x16 oacc[QPW][2];
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         //      tiles the score registers would not fit and each tile is multiplied right before its softmax ----
         constexpr bool S_FIRST = QPW <= 2;
         f32x16 sacc[S_FIRST ? QPW : 1][2];
-        auto scores = [&](int qi, f32x16(&sa)[2]) {
+        auto scores = [&](const bf16x8(&qfr)[4], f32x16(&sa)[2]) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 if (kb == 1 && !both_halves) continue;
@@ -234,19 +252,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
-                    sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qi][s], sa[kb], 0, 0, 0);
+                    sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfr[s], sa[kb], 0, 0, 0);
                 }
             }
         };
         if constexpr (S_FIRST) {
 #pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) scores(qi, sacc[qi]);
+            for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi]);
         }
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
-            if constexpr (!S_FIRST) scores(qi, sa);
+            if constexpr (!S_FIRST) scores(qf[qi], sa);
             // ---- online softmax (this lane: one query, 32 of the tile's 64 keys); exponent = fma(s, c, -m c) ----
             float mx = -INFINITY;
             if (tail) {
@@ -302,12 +320,86 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 }
             }
         }
+        if constexpr (XQ) {
+            if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
+                f32x16 sx[2];
+                scores(qx, sx);
+                if (tail) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                            if (key >= L) sx[kb][i] = -INFINITY;
+                        }
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sx[kb][i]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // finite: key kv0 of every tile is a real key
+                float psum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float e = fast_exp2(fmaf(sx[kb][i], sc, -mx));
+                        sx[kb][i] = e;
+                        psum += e;
+                    }
+                }
+                f32x16 ox[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { ox[0][i] = 0.f; ox[1][i] = 0.f; }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8 pf = pack8(sx[kb], 8 * s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 vf = load_vt_frag<VTR>(v_lds, kb * 32 + 16 * s2, db, lane, VROWB);
+                            ox[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ox[db], 0, 0, 0);
+                        }
+                    }
+                }
+                if (r < L - XQ0) {  // this lane's query is a real row: its 32 d-values, the tile's max and its half of the sum
+                    float* dst = xq_lds + (t * XQ_ROWS + r) * (HD + 4);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) dst[db * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = ox[db][i];
+                    dst[HD + 1 + h] = psum;
+                    if (h == 0) dst[HD] = mx;
+                }
+            }
+        }
         MERV_STAMP(5 + 4 * t);
     }
     MERV_STAMP(30);
 
     // ---- output: transpose each 32 x 64 tile through LDS so the global stores are 16 B per lane, 128 B per row ----
-    __syncthreads();  // every wave is done with the K/V tiles
+    __syncthreads();  // every wave is done with the K/V tiles (and, XQ, has left its partials of the extra rows)
+    if constexpr (XQ) {
+        // merge the key-tile partials of extra row `row`: lane = output column
+        for (int row = wave; row < L - XQ0; row += NW) {
+            float m = -INFINITY;
+            for (int t = 0; t < ntiles; ++t) m = fmaxf(m, xq_lds[(t * XQ_ROWS + row) * (HD + 4) + HD]);
+            float o = 0.f, l = 0.f;
+            for (int t = 0; t < ntiles; ++t) {
+                const float* src = xq_lds + (t * XQ_ROWS + row) * (HD + 4);
+                const float w = fast_exp2(src[HD] - m);
+                o = fmaf(w, src[lane], o);
+                l = fmaf(w, src[HD + 1] + src[HD + 2], l);
+            }
+            p.out[((size_t)seq * L + XQ0 + row) * D + head * HD + lane] = f2bf(o / l);
+        }
+    }
     char* stg = smem + wave * (32 * 128);
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
@@ -499,14 +591,14 @@ static bool use_vtr() {
     return !(e && e[0] == '0');
 }
 
-template <int NW, int QPW>
+template <int NW, int QPW, bool XQ = false>
 static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
     const int rows = NW * QPW * 32;
-    dim3 grid((a.L + rows - 1) / rows, a.heads, a.nseq);
+    dim3 grid(XQ ? 1 : (a.L + rows - 1) / rows, a.heads, a.nseq);
     if (use_vtr())
-        hipLaunchKernelGGL((attn_kernel<true, NW, QPW>), grid, dim3(NW * 64), 0, s, a);
+        hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ>), grid, dim3(NW * 64), 0, s, a);
     else
-        hipLaunchKernelGGL((attn_kernel<false, NW, QPW>), grid, dim3(NW * 64), 0, s, a);
+        hipLaunchKernelGGL((attn_kernel<false, NW, QPW, XQ>), grid, dim3(NW * 64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -523,6 +615,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (force && force[0] == '3') return launch_attn_cfg<3, 3>(a, s);
     if (force && force[0] == '4') return launch_attn_cfg<4, 2>(a, s);
     if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
+    // 8 full tiles + 1..8 rows (257 / 261 tokens): 4 x 2 block, the extra rows split over the waves by key tile
+    if (a.L > 256 && a.L <= 256 + XQ_ROWS && !a.mx_q) return launch_attn_cfg<4, 2, true>(a, s);
     if (a.L >= 1024) return launch_attn_cfg<4, 2>(a, s);
     const int pad9 = (t32 + 8) / 9 * 9 - t32, pad8 = (t32 + 7) / 8 * 8 - t32;
     if (pad9 < pad8) return launch_attn_cfg<3, 3>(a, s);

@@ -644,6 +644,20 @@ extern "C" int merv_debug_gemm_mx_out(const void* A, const void* W, void* C_unus
     return 0;
 }
 
+// test hook: merv_gemm_bf16's epilogue set plus the LayerNorm-partials output the encoder requests from the GEMMs that write
+// its residual stream (GemmArgs::stats_out): lets the parity tests check the epilogue statistics through the C ABI.
+extern "C" int merv_debug_gemm_stats(const void* A, const void* W, void* C, const float* bias, const float* lscale, const void* res,
+                                     int32_t M, int32_t N, int32_t K, int32_t act, float* stats_out, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(A && W && C && stats_out, "merv_debug_gemm_stats: null argument");
+    MERV_CHECK(K > 0 && K % 64 == 0 && N > 0 && N % 128 == 0, "merv_debug_gemm_stats: K % 64 == 0 and N % 128 == 0 required");
+    MERV_CHECK(act >= ACT_NONE && act <= ACT_QUICK_GELU, "merv_debug_gemm_stats: unknown activation");
+    GemmArgs g = gemm_args((const bf16_t*)A, K, W, K, (bf16_t*)C, N, M, N, bias, act);
+    g.lscale = lscale; g.res = (const bf16_t*)res; g.ldres = N; g.stats_out = stats_out;
+    MERV_HIP(launch_gemm(g, (hipStream_t)stream_));
+    return 0;
+}
+
 // ---- frame preprocessing (row a3) ----
 extern "C" size_t merv_preprocess_workspace_bytes(int32_t T, int32_t H, int32_t W, int32_t out_size) {
     if (T <= 0 || H <= 0 || W <= 0 || out_size <= 0) return 0;

@@ -89,9 +89,13 @@ class LlamaBackbone:
     @torch.inference_mode()
     def generate_from_embeds(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 32, do_sample: bool = False,
                              temperature: float = 1.0, eos_token_id: Optional[int] = None,
-                             generator: Optional[torch.Generator] = None, use_graph: bool = True) -> torch.LongTensor:
+                             generator: Optional[torch.Generator] = None, use_graph: bool = True, top_k: int = 0,
+                             top_p: float = 1.0, repetition_penalty: float = 1.0, min_new_tokens: int = 0) -> torch.LongTensor:
         """Prefill on `inputs_embeds` [B, S, D] (merv.py:723-734), then decode token by token on the KV cache
-        (merv.py:524-538). Returns the new token ids [B, <= max_new_tokens]."""
+        (merv.py:524-538). Returns the new token ids [B, <= max_new_tokens]. Decoding controls are the subset of HF
+        `generate` kwargs the reference's scripts pass through (merv.py:818-825): greedy or sampling with `temperature`,
+        `top_k`, `top_p`, plus `repetition_penalty` over the generated tokens (HF's logits processors, same order:
+        penalty -> temperature -> top-k -> top-p)."""
         if use_graph and inputs_embeds.is_cuda and inputs_embeds.shape[1] + max_new_tokens + 1 <= self.config.max_position_embeddings:
             # static-cache prefill + hipGraph-replayed decode steps (StaticDecoder above)
             need = inputs_embeds.shape[1] + max_new_tokens + 1
@@ -117,9 +121,24 @@ class LlamaBackbone:
         new_tokens = []
         done = torch.zeros(inputs_embeds.shape[0], dtype=torch.bool, device=inputs_embeds.device)
         for i in range(max_new_tokens):
+            if eos_token_id is not None and i < min_new_tokens:  # HF MinLength / MinNewTokensLength processors
+                logits = logits.clone()
+                logits[:, eos_token_id] = float("-inf")
+            if repetition_penalty != 1.0 and new_tokens:  # HF RepetitionPenaltyLogitsProcessor over the tokens generated so far
+                prev = torch.stack(new_tokens, 1)
+                sel = logits.gather(1, prev)
+                logits = logits.scatter(1, prev, torch.where(sel < 0, sel * repetition_penalty, sel / repetition_penalty))
             if do_sample:
-                probs = torch.softmax(logits / max(temperature, 1e-6), dim=-1)
-                nxt = torch.multinomial(probs, 1, generator=generator)[:, 0]
+                lg = logits / max(temperature, 1e-6)
+                if top_k and top_k > 0:  # HF TopKLogitsWarper
+                    kth = lg.topk(min(top_k, lg.shape[-1]), dim=-1).values[:, -1:]
+                    lg = lg.masked_fill(lg < kth, float("-inf"))
+                if top_p < 1.0:  # HF TopPLogitsWarper: drop the low tail whose cumulative probability is <= 1 - top_p
+                    srt, idx = lg.sort(dim=-1, descending=False)
+                    drop = srt.softmax(-1).cumsum(-1) <= (1.0 - top_p)
+                    drop[:, -1] = False
+                    lg = lg.masked_fill(drop.scatter(1, idx, drop), float("-inf"))
+                nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator)[:, 0]
             else:
                 nxt = logits.argmax(-1)
             new_tokens.append(nxt)

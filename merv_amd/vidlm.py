@@ -8,6 +8,7 @@ path. The LLM stays outside (PyTorch-ROCm): `forward_visual` returns what MERV.f
 from __future__ import annotations
 
 import re
+from pathlib import Path
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -198,7 +199,32 @@ class MERV(MERVVisual):
         clip_start_sec = kwargs.pop("clip_start_sec", 0.0)
         clip_end_sec = kwargs.pop("clip_end_sec", None)
         end_frame = kwargs.pop("end_frame", None)
-        if video is not None:
+        max_new = kwargs.pop("max_new_tokens", 32)
+        gen = dict(max_new_tokens=max_new, do_sample=kwargs.pop("do_sample", False), temperature=kwargs.pop("temperature", 1.0),
+                   top_k=kwargs.pop("top_k", 0) or 0, top_p=kwargs.pop("top_p", 1.0), repetition_penalty=kwargs.pop("repetition_penalty", 1.0))
+        # HF generate kwargs the reference forwards (merv.py:818-825) that change nothing here, or that this explicit
+        # prefill + decode loop does not implement: the former are accepted, the latter fail loudly instead of silently
+        # decoding differently from the reference's eval scripts
+        for k in ("use_cache", "pad_token_id", "attention_mask", "is_image", "return_dict_in_generate"):
+            kwargs.pop(k, None)
+        if kwargs.pop("num_beams", 1) not in (None, 1):
+            raise NotImplementedError("beam search (num_beams > 1) is not implemented by merv_amd's decode loop")
+        # HF MinLengthLogitsProcessor counts the prompt's input_ids (the reference passes input_ids, merv.py:819): EOS is
+        # barred while prompt + generated < min_length (every reference script passes min_length=1: a no-op)
+        gen["min_new_tokens"] = max(int(kwargs.pop("min_new_tokens", 0) or 0), int(kwargs.pop("min_length", 0) or 0) - input_ids.shape[1])
+        if kwargs:
+            raise TypeError(f"generate(): unsupported generation arguments {sorted(kwargs)}")
+        max_len = getattr(self.llm_backbone, "llm_max_length", None)
+        if max_len:  # tokenizer(prompt_text, truncation=True): HF truncates to the tokenizer's model_max_length (merv.py:786)
+            input_ids = input_ids[:, :max_len]
+        if video is not None and isinstance(video, (str, Path)) and ".jpg" in str(video):  # still image (merv.py:787-793)
+            import numpy as np
+            from PIL import Image
+            image = Image.open(str(video)).convert("RGB")
+            frames = torch.from_numpy(np.array(image).transpose(2, 0, 1)[None,].repeat(max(num_frames), 0)).to(dev)
+            video_values = [vb.video_transform(frames[:: max(num_frames) // nf].contiguous()).unsqueeze(0)
+                            for vb, nf in zip(self.video_backbones, num_frames)]
+        elif video is not None:
             frames = load_video(video, clip_start_sec=clip_start_sec, clip_end_sec=clip_end_sec, num_frames=max(num_frames),
                                 end_frame=end_frame).to(dev)  # uint8 [T,3,H,W]
             video_values = []
@@ -210,10 +236,7 @@ class MERV(MERVVisual):
         emb = self.llm_backbone.embed_input_ids(input_ids)
         bos = 1 if getattr(self.llm_backbone.config, "bos_token_id", None) is not None else 0  # merv.py:521
         fused_emb, _, _, weights = self.forward_visual(video_values, emb, bos_token_length=bos)
-        max_new = kwargs.pop("max_new_tokens", 32)
-        ids = self.llm_backbone.generate_from_embeds(fused_emb, max_new_tokens=max_new, do_sample=kwargs.pop("do_sample", False),
-                                                     temperature=kwargs.pop("temperature", 1.0),
-                                                     eos_token_id=getattr(self.llm_backbone.config, "eos_token_id", None))
+        ids = self.llm_backbone.generate_from_embeds(fused_emb, eos_token_id=getattr(self.llm_backbone.config, "eos_token_id", None), **gen)
         self.last_fusion_weights = weights
         if self.tokenizer is not None and hasattr(self.tokenizer, "decode"):
             return self.tokenizer.decode(ids[0].tolist()).strip()

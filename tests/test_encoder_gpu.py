@@ -129,3 +129,27 @@ def test_ln_fold_at_split_gemm_sizes(dev):
     folded = HipEncoder(spec, W, dev).forward(pix).float()
     per_video = ((folded - plain).flatten(1).norm(dim=1) / plain.flatten(1).norm(dim=1)).cpu()
     assert float(per_video.max()) < 1.5e-2, per_video  # the last video's rows are the ones behind the split
+
+
+@pytest.mark.parametrize("name", ["languagebind", "dinov2", "vivit", "siglip"])
+def test_batch8_last_video_vs_oracle(dev, name):
+    """At 8 videos per step (the bench's batch) every block GEMM takes the round-filling split: complete rounds on the
+    eight-phase kernel, the remaining rows (LanguageBind 128, DINOv2 640, ViViT / SigLIP ~3330) on a second launch -- K-sliced
+    over idle CUs when they are few -- with the folded-LayerNorm statistics and partials offset by the rows the first launch
+    took. Those rows belong to the LAST video: it is compared with the oracle run on that video alone (videos are
+    independent), two blocks deep so that the statistics a GEMM's epilogue leaves are consumed by the next block."""
+    import dataclasses
+    from oracle import merv_oracle as O
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    spec = dataclasses.replace(next(s for s in merv_full_specs() if s.name == name), layers=2)
+    W = random_weights(spec, seed=31)
+    g = torch.Generator().manual_seed(8)
+    pix = torch.randn(spec.pixel_shape(8), generator=g)
+    cfg = O.EncoderCfg(**{k: getattr(spec, k) for k in O.EncoderCfg.__dataclass_fields__})
+    ref = O.encoder_forward(pix[7:8], cfg, W)
+    out = HipEncoder(spec, W, dev).forward(pix.to(dev))
+    torch.cuda.synchronize()
+    err, cos = rel_l2(out[7:8], ref), _min_cos(out[7:8], ref)
+    print(f"{name} B=8 last video: rel_l2={err:.4e} min_cos={cos:.6f}")
+    assert err < 2e-2 and cos > 0.999, (name, err, cos)

@@ -54,3 +54,36 @@ def test_split_launch_carries_row_offsets_of_optional_epilogue_inputs(dev):
     check(lib.merv_debug_gemm_mx_out(ptr(a), ptr(w), ptr(out), M, N, K, ptr(q2), ptr(sc2), torch.cuda.current_stream(dev).cuda_stream),
           "merv_debug_gemm_mx_out")
     assert torch.equal(q2, q) and torch.equal(ops.mxfp8_scales_to_rows(sc2, M, N), ops.mxfp8_scales_to_rows(sc, M, N))
+
+
+@pytest.mark.parametrize("M,N,K,act", [(128, 1024, 4096, "none"), (640, 1024, 1024, "none"), (33000, 1024, 256, "none"),
+                                       (100, 768, 3072, "gelu_tanh"), (640, 4096, 1024, "gelu_erf"), (33, 256, 1024, "quick_gelu")])
+def test_epilogue_layernorm_partials(dev, M, N, K, act):
+    """The LayerNorm partials a GEMM's epilogue leaves for a LayerNorm folded into the next GEMM: {sum, M2} per 64 columns of
+    the bf16-rounded output row (every tile configuration shares the epilogue; 33000 rows take the round-filling split, whose
+    second launch must offset the partials by the rows the first one took). Combined by Chan's rule they must give the row
+    mean / variance of what was stored; rows are given an offset so that mean >> 0."""
+    import torch.nn.functional as F
+    from merv_amd import _lib
+    from merv_amd._lib import ACT, check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ls = (0.5 + torch.rand(N, generator=g)).to(dev)
+    x = (torch.randn(M, N, generator=g) + 0.7).to(torch.bfloat16).to(dev)
+    fn = {"none": lambda t: t, "gelu_erf": F.gelu, "gelu_tanh": lambda t: F.gelu(t, approximate="tanh"),
+          "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    ref = x.float() + ls * fn(a.float() @ w.float().t() + bias)
+    parts = torch.full((M, N // 64, 2), float("nan"), device=dev)
+    out = x.clone()
+    check(lib.merv_debug_gemm_stats(ptr(a), ptr(w), ptr(out), ptr(bias), ptr(ls), ptr(out), M, N, K, ACT[act], ptr(parts),
+                                    torch.cuda.current_stream(dev).cuda_stream), "merv_debug_gemm_stats")
+    assert rel_l2(out, ref) < 6e-3, (M, N, K, act)
+    o = out.float()
+    assert torch.isfinite(parts).all()
+    mean = parts[..., 0].sum(1) / N
+    m2 = (parts[..., 1] + 64 * (parts[..., 0] / 64 - mean[:, None]) ** 2).sum(1)
+    assert torch.allclose(mean, o.mean(1), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m2 / N, o.var(1, unbiased=False), rtol=1e-3, atol=1e-6)

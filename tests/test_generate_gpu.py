@@ -14,7 +14,7 @@ class ByteTokenizer:
         return bytes([max(0, min(255, i - 3)) for i in ids]).decode("latin-1")
 
 
-def _model(dev, ids, frames, tokenizer=None):
+def _model(dev, ids, frames, tokenizer=None, vfl=1024):
     from merv_amd.backbones import VIDEO_BACKBONES
     from merv_amd.llm import LlamaBackbone
     from merv_amd.vidlm import MERV
@@ -23,7 +23,7 @@ def _model(dev, ids, frames, tokenizer=None):
     llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
                              num_key_value_heads=4, max_position_embeddings=4096, bos_token_id=1, eos_token_id=2, pad_token_id=0),
                         device=dev)
-    return MERV(bbs, llm, tokenizer=tokenizer, visual_feature_length=1024)
+    return MERV(bbs, llm, tokenizer=tokenizer, visual_feature_length=vfl)
 
 
 def test_generate_merv_full_shape(dev):
@@ -84,3 +84,38 @@ def test_graph_decode_matches_eager_static_decode(dev):
         hf = bb.llm(inputs_embeds=emb).logits[:, -1].float()
     mine = StaticDecoder(bb.llm, 64, 1).prefill(emb)
     assert float((mine - hf).norm() / hf.norm()) < 2e-2
+
+
+def test_generate_still_image_and_decoding_kwargs(dev, tmp_path):
+    """merv.py:787-793: a `.jpg` path is a still image repeated max(num_frames) times, then the per-encoder stride. And the
+    kwargs the reference's scripts pass (scripts/quick_start.py:24-32, eval_mcq.py:146-153: do_sample, temperature,
+    max_new_tokens, min_length) are honoured; an argument the decode loop does not implement fails loudly."""
+    import numpy as np
+    from PIL import Image
+    m = _model(dev, ["dinov2-video-all-tokens", "siglip-vit-b16-224px-all-no-cls"], [4, 4], vfl=256)
+    m.tokenizer = None
+    img = (np.random.default_rng(0).integers(0, 256, (96, 128, 3))).astype(np.uint8)
+    path = tmp_path / "frame.jpg"
+    Image.fromarray(img).save(path, quality=95)
+    ids = m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=4, do_sample=False, temperature=1.0, min_length=1)
+    assert ids.shape == (1, 4)
+    # the same thing by hand: decode the jpeg once, repeat, stride, transform
+    dec = torch.from_numpy(np.array(Image.open(path).convert("RGB")).transpose(2, 0, 1)[None].repeat(4, 0)).to(dev)
+    vv = [vb.video_transform(dec[:: 4 // nf].contiguous())[None] for vb, nf in zip(m.video_backbones, [4, 4])]
+    fused, _ = m.encode(vv)
+    fused = fused.clone()
+    emb = m.llm_backbone.embed_input_ids(torch.tensor([[1, 9, 8]], device=dev))
+    full = torch.cat([emb[:, :1], fused.to(emb.dtype), emb[:, 1:]], 1)
+    first = int(m.llm_backbone.llm(inputs_embeds=full).logits[:, -1].argmax(-1))
+    assert int(ids[0, 0]) == first
+    # sampling controls: top_k = 1 is greedy whatever the temperature; a seeded sampler repeats
+    assert torch.equal(m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=4, do_sample=True, temperature=0.7, top_k=1), ids)
+    a = m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=6, do_sample=True, temperature=0.9, top_p=0.8, repetition_penalty=1.2)
+    assert a.shape[1] <= 6 and int(a.max()) < 320
+    # min_length counts the prompt: EOS (id 2) cannot appear among the first tokens
+    b = m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=5, min_length=3 + 5)
+    assert b.shape == (1, 5) and not bool((b == 2).any())
+    with pytest.raises(NotImplementedError):
+        m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=2, num_beams=4)
+    with pytest.raises(TypeError, match="unsupported generation arguments"):
+        m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=2, length_penalty=2.0)

@@ -169,6 +169,36 @@ def test_attention_spiked_max(dev):
 
 
 @pytest.mark.parametrize("vtr", ["1", "0"])
+@pytest.mark.parametrize("L", [257, 258, 261, 264, 265])
+def test_attention_extra_rows_split_over_key_tiles(dev, vtr, L):
+    """257 / 261-token sequences run 8 full query tiles on a 4 x 2 block; the 1..8 rows past them are multiplied against one
+    key tile per wave and merged through LDS (attention.hip, XQ). A whole-tensor norm would hide one wrong row in 257, so
+    the extra rows are checked on their own -- with a score spike in an early AND a late key tile for the first extra row, so
+    the partials being merged carry very different maxima (265 rows fall back to the 3 x 3 block: same checks)."""
+    from merv_amd import ops
+    os.environ["MERV_ATTN_VTR"] = vtr
+    try:
+        nseq, heads = 3, 4
+        g = torch.Generator().manual_seed(L)
+        qkv = torch.randn(nseq * L, 3 * heads * 64, generator=g) * 1.2
+        D = heads * 64
+        qkv[L + 256, 64:128] = 3.0                 # sequence 1, head 1: query row 256 ...
+        qkv[L + 5, D + 64:D + 128] = 3.0           # ... loves key 5 (tile 0): score 3*3*64/8 = 72
+        qkv[L + 200, D + 64:D + 128] = 2.9         # ... and key 200 (tile 3) almost as much
+        qkv = _bf(qkv).to(dev)
+        out = ops.attention(qkv, nseq, L, heads).float().cpu().reshape(nseq, L, D)
+        ref = _attn_ref(qkv, nseq, L, heads).float().cpu().reshape(nseq, L, D)
+        assert torch.isfinite(out).all()
+        assert rel_l2(out, ref) < 1e-2
+        assert rel_l2(out[:, 256:], ref[:, 256:]) < 1e-2, (vtr, L)
+        assert rel_l2(out[1, 256, 64:128], ref[1, 256, 64:128]) < 1e-2
+        per_row = ((out - ref).norm(dim=-1) / (ref.norm(dim=-1) + 1e-20))
+        assert float(per_row.max()) < 3e-2, (vtr, L, int(per_row.argmax()))
+    finally:
+        os.environ.pop("MERV_ATTN_VTR", None)
+
+
+@pytest.mark.parametrize("vtr", ["1", "0"])
 @pytest.mark.parametrize("nclips,ntok,heads", [(1, 4, 1), (2, 257, 16), (1, 3, 2), (3, 17, 4)])
 def test_temporal_attention(dev, vtr, nclips, ntok, heads):
     from merv_amd import ops
