@@ -1,0 +1,287 @@
+// Batch-1 token decode kernels for the LLM hand-off (merv/models/vidlms/merv.py:818-825 ->
+// HF GenerationMixin's per-token forward of LlamaForCausalLM / MistralForCausalLM, transformers modeling_llama).
+//
+// The north_star keeps the LLM *prefill* on PyTorch-ROCm. A decode step, though, is ~1100 tiny PyTorch kernels per token
+// (RMSNorm = 8 launches, rotary embedding = 10, ...): measured on MI355X, 6.1 of the 10.4 ms of a graph-replayed
+// Llama-2-7B step are those launches, 4.7 ms the library's M = 1 GEMMs at 2.4-3.4 TB/s (tools/probes/decode_breakdown.py).
+// These kernels are the step as 11 launches per layer, every one a pure HBM stream:
+//
+//   rmsnorm_kernel         y = w * bf16(x * rsqrt(mean(x^2) + eps))                    (LlamaRMSNorm.forward)
+//   gemv_kernel            y = bf16(W x) [+ residual]      W [N, K] bf16 streamed once (nn.Linear, M = 1)
+//   gemv_silu_mul_kernel   y = bf16(silu(bf16(Wg x))) * bf16(Wu x)                      (LlamaMLP: act_fn(gate) * up)
+//   rope_cache_kernel      q, k <- rotary(pos); K / V cache[pos] <- k, v              (apply_rotary_pos_emb + cache update)
+//   decode_attn_kernel     one query per head against cache[0 .. pos], split over positions, (m, l, o) partials
+//   decode_attn_merge_kernel  merges the partials                                      (flash-decoding)
+//
+// Rounding points follow the bf16 module: every nn.Linear output, every elementwise result is rounded to bf16 where the
+// PyTorch graph materialises a bf16 tensor; accumulation and softmax are fp32. The position is read from device memory
+// (one int64), so a step captured in a hipGraph replays for every position.
+#include "common.h"
+#include "kernels.h"
+
+namespace merv {
+namespace {
+
+MERV_DEVICE float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MERV_DEVICE void unpack8f(const u32x4& p, float (&f)[8]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { f[2 * q] = bflo(p[q]); f[2 * q + 1] = bfhi(p[q]); }
+}
+MERV_DEVICE float round_bf(float x) { return bf2f(f2bf(x)); }
+
+// ---- RMSNorm: one wave per row ----
+__global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const bf16_t* x = p.x + (size_t)row * p.D;
+    const int nchunk = p.D >> 3;
+    float ss = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        float f[8];
+        unpack8f(*(const u32x4*)(x + c * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+    const float rstd = rsqrtf(wave_sum64(ss) / (float)p.D + p.eps);
+    bf16_t* y = p.y + (size_t)row * p.D;
+    for (int c = lane; c < nchunk; c += 64) {
+        float f[8], w[8];
+        unpack8f(*(const u32x4*)(x + c * 8), f);  // second read: L1 / L2 resident
+        unpack8f(*(const u32x4*)(p.w + c * 8), w);
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // weight * hidden.to(bf16): two roundings, as the module
+            o[q] = pack2bf(w[2 * q] * round_bf(f[2 * q] * rstd), w[2 * q + 1] * round_bf(f[2 * q + 1] * rstd));
+        *(u32x4*)(y + c * 8) = o;
+    }
+}
+
+// ---- GEMV: W [N, K] bf16 row-major streamed once; each wave owns ROWS output rows, lanes stride K in 16-byte chunks ----
+constexpr int GEMV_ROWS = 2;   // rows per wave (x chunk reused across them)
+constexpr int GEMV_WAVES = 4;  // waves per block
+
+template <int NW_MATS>  // 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x)
+__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * GEMV_WAVES + wave) * GEMV_ROWS;
+    if (n0 >= p.N) return;
+    const int nchunk = p.K >> 3;
+    float acc[NW_MATS][GEMV_ROWS];
+#pragma unroll
+    for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r) acc[m][r] = 0.f;
+    const bf16_t* wrow[NW_MATS][GEMV_ROWS];
+#pragma unroll
+    for (int r = 0; r < GEMV_ROWS; ++r) {
+        const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+        wrow[0][r] = p.W + (size_t)n * p.K;
+        if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
+    }
+    // 4 chunks per lane per trip: 4 x ROWS x NW_MATS weight loads of 16 B in flight per lane before the first use
+    constexpr int UN = 4;
+    int c = lane;
+    for (; c + 64 * (UN - 1) < nchunk; c += 64 * UN) {
+        u32x4 xv[UN], wv[NW_MATS][GEMV_ROWS][UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+                for (int r = 0; r < GEMV_ROWS; ++r)
+                    wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + (c + 64 * u) * 8));
+            xv[u] = *(const u32x4*)(p.x + (c + 64 * u) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            float xf[8];
+            unpack8f(xv[u], xf);
+#pragma unroll
+            for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+                for (int r = 0; r < GEMV_ROWS; ++r) {
+                    float wf[8];
+                    unpack8f(wv[m][r][u], wf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m][r] = fmaf(wf[j], xf[j], acc[m][r]);
+                }
+        }
+    }
+    for (; c < nchunk; c += 64) {
+        float xf[8];
+        unpack8f(*(const u32x4*)(p.x + c * 8), xf);
+#pragma unroll
+        for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+            for (int r = 0; r < GEMV_ROWS; ++r) {
+                float wf[8];
+                unpack8f(__builtin_nontemporal_load((const u32x4*)(wrow[m][r] + c * 8)), wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m][r] = fmaf(wf[j], xf[j], acc[m][r]);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r) acc[m][r] = wave_sum64(acc[m][r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r) {
+            const int n = n0 + r;
+            if (n >= p.N) break;
+            float v = round_bf(acc[0][r]);  // the nn.Linear output as a bf16 tensor
+            if constexpr (NW_MATS == 2) {
+                const float g = v;
+                const float s = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor
+                v = s * round_bf(acc[1][r]);
+            } else if (p.res) {
+                v = v + bf2f(p.res[n]);  // x + linear(...), rounded once more below
+            }
+            if (p.y32) p.y32[n] = v;  // logits: .float() of the bf16 linear output
+            else p.y[n] = f2bf(v);
+        }
+    }
+}
+
+// ---- rotary embedding of q and k at the current position + cache update ----
+// q [H * hd], k [Hkv * hd], v [Hkv * hd] bf16; cos / sin tables [max_len, hd] bf16 (HF: emb = cat(freqs, freqs));
+// caches [Hkv, max_len, hd]. q_embed = q * cos + rotate_half(q) * sin with bf16 rounding of each product and of the sum.
+__global__ __launch_bounds__(256) void rope_cache_kernel(DecodeRopeArgs p) {
+    const long pos = *p.pos;
+    const int hd = p.hd, half = hd >> 1;
+    const int total = (p.H + 2 * p.Hkv) * hd;
+    const bf16_t* cs = p.cos + pos * hd;
+    const bf16_t* sn = p.sin + pos * hd;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int head = i / hd, d = i - head * hd;
+        if (head < p.H + p.Hkv) {
+            bf16_t* vec = head < p.H ? p.q + head * hd : p.k + (head - p.H) * hd;
+            const float a = bf2f(vec[d]);
+            const float b = d < half ? -bf2f(vec[d + half]) : bf2f(vec[d - half]);  // rotate_half
+            const float r = round_bf(round_bf(a * bf2f(cs[d])) + round_bf(b * bf2f(sn[d])));
+            // q is rotated in place AFTER every thread of its head has read: write to the separate output instead
+            if (head < p.H) p.q_out[i] = f2bf(r);
+            else p.k_cache[((size_t)(head - p.H) * p.max_len + pos) * hd + d] = f2bf(r);
+        } else {
+            const int hv = head - p.H - p.Hkv;
+            p.v_cache[((size_t)hv * p.max_len + pos) * hd + d] = p.v[hv * hd + d];
+        }
+    }
+}
+
+// ---- decode attention: grid (H, nsplit); 16 lanes per cache position (16 B of a 128-wide K / V row each; hd == 128) ----
+// Each block takes positions [s * chunk, (s + 1) * chunk) of [0, pos]; every 16-lane group keeps a running (m, l, o[8]);
+// groups and waves are merged through LDS; the block writes (m, l, o[hd]) to the workspace.
+constexpr int DA_THREADS = 256;
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(DecodeAttnArgs p) {
+    __shared__ float sm_m[16], sm_l[16];
+    __shared__ __attribute__((aligned(16))) float sm_o[16][128];
+    const int h = blockIdx.x, s = blockIdx.y;
+    const int hkv = h / (p.H / p.Hkv);
+    const long npos = *p.pos + 1;  // positions 0 .. pos hold keys (the current token's k / v were just written)
+    const int chunk = (int)((npos + p.nsplit - 1) / p.nsplit);
+    const int j0 = s * chunk, j1 = (long)(j0 + chunk) < npos ? j0 + chunk : (int)npos;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;  // 16 lanes per position, 8 dims per lane
+    const int g = wave * 4 + grp;                // 16 groups per block
+    float qf[8];
+    unpack8f(*(const u32x4*)(p.q + h * 128 + sub * 8), qf);
+    const bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
+    const bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
+    float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;
+    for (int j = j0 + g; j < j1; j += 16) {
+        float kf[8], vf[8];
+        unpack8f(*(const u32x4*)(Kc + (size_t)j * 128 + sub * 8), kf);
+        unpack8f(*(const u32x4*)(Vc + (size_t)j * 128 + sub * 8), vf);
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d = fmaf(qf[i], kf[i], d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+        d *= sc;
+        const float mn = fmaxf(m, d);
+        const float a = __builtin_amdgcn_exp2f(m - mn), e = __builtin_amdgcn_exp2f(d - mn);
+        l = l * a + e;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf(o[i], a, e * vf[i]);
+        m = mn;
+    }
+    if (sub == 0) { sm_m[g] = m; sm_l[g] = l; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm_o[g][sub * 8 + i] = o[i];
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int d = threadIdx.x;
+        float M = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) M = fmaxf(M, sm_m[q]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float w = sm_m[q] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_m[q] - M);
+            L = fmaf(w, sm_l[q], L);
+            O = fmaf(w, sm_o[q][d], O);
+        }
+        float* ws = p.ws + ((size_t)h * p.nsplit + s) * (128 + 2);
+        ws[d] = O;
+        if (d == 0) { ws[128] = M; ws[129] = L; }
+    }
+}
+
+__global__ __launch_bounds__(128) void decode_attn_merge_kernel(DecodeAttnArgs p) {
+    const int h = blockIdx.x, d = threadIdx.x;
+    const float* ws = p.ws + (size_t)h * p.nsplit * (128 + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, ws[s * 130 + 128]);
+    float L = 0.f, O = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const float ms = ws[s * 130 + 128];
+        const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+        L = fmaf(w, ws[s * 130 + 129], L);
+        O = fmaf(w, ws[s * 130 + d], O);
+    }
+    p.out[h * 128 + d] = f2bf(O / L);
+}
+
+}  // namespace
+
+hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.D % 8 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
+    if (a.N <= 0 || a.K <= 0 || a.K % 8 != 0) return hipErrorInvalidValue;
+    const int rows_per_block = GEMV_ROWS * GEMV_WAVES;
+    dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
+    if (a.W2) hipLaunchKernelGGL(gemv_kernel<2>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s) {
+    if (a.hd % 2 != 0 || a.H <= 0 || a.Hkv <= 0) return hipErrorInvalidValue;
+    const int total = (a.H + 2 * a.Hkv) * a.hd;
+    hipLaunchKernelGGL(rope_cache_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
+    if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    hipLaunchKernelGGL(decode_attn_merge_kernel, dim3(a.H), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace merv
