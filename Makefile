@@ -4,7 +4,7 @@ ARCH  ?= gfx950
 CSRC  := merv_amd/csrc
 LIB   := merv_amd/lib/libmerv_hip.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Iinclude
-HIP_SRCS := $(CSRC)/gemm.hip $(CSRC)/attention.hip $(CSRC)/rowops.hip $(CSRC)/preproc.hip $(CSRC)/backward.hip $(CSRC)/mxfp8.hip $(CSRC)/capi.hip
+HIP_SRCS := $(CSRC)/gemm.hip $(CSRC)/attention.hip $(CSRC)/rowops.hip $(CSRC)/preproc.hip $(CSRC)/backward.hip $(CSRC)/mxfp8.hip $(CSRC)/decode.hip $(CSRC)/capi.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 
 all: lib oracle

@@ -757,3 +757,69 @@ extern "C" int merv_pool3d(const void* tokens, void* out, int32_t B, int32_t T, 
     MERV_HIP(launch_pool(pa, (hipStream_t)stream_));
     return 0;
 }
+
+// ---- batch-1 token decode (row f-3): the per-token forward of LlamaForCausalLM / MistralForCausalLM as HBM streams ----
+extern "C" int merv_decode_rmsnorm(const void* x, const void* w, void* y, int32_t rows, int32_t D, float eps, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(x && w && y, "merv_decode_rmsnorm: null argument");
+    MERV_CHECK(rows > 0 && D > 0 && D % 8 == 0, "merv_decode_rmsnorm: rows > 0 and D % 8 == 0 required");
+    DecodeRmsArgs a{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rows, D, eps};
+    MERV_HIP(launch_decode_rmsnorm(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_decode_gemv(const void* W, const void* W2, const void* x, const void* res, void* y, float* y32, int32_t N,
+                                int32_t K, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(W && x && (y || y32), "merv_decode_gemv: null argument");
+    MERV_CHECK(N > 0 && K > 0 && K % 8 == 0, "merv_decode_gemv: N > 0 and K % 8 == 0 required");
+    MERV_CHECK(!(W2 && res), "merv_decode_gemv: the gated form takes no residual");
+    MERV_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && (!W2 || ((uintptr_t)W2 & 15) == 0), "merv_decode_gemv: 16-byte alignment required");
+    DecodeGemvArgs a{};
+    a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.x = (const bf16_t*)x; a.res = (const bf16_t*)res; a.y = (bf16_t*)y; a.y32 = y32;
+    a.N = N; a.K = K;
+    MERV_HIP(launch_decode_gemv(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_decode_gemv3(const void* Wa, const void* Wb, const void* Wc, const void* x, void* ya, void* yb, void* yc,
+                                 int32_t Na, int32_t Nb, int32_t Nc, int32_t K, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(Wa && Wb && Wc && x && ya && yb && yc, "merv_decode_gemv3: null argument");
+    MERV_CHECK(Na > 0 && Nb > 0 && Nc > 0 && Na % 2 == 0 && Nb % 2 == 0 && Nc % 2 == 0 && K > 0 && K % 8 == 0,
+               "merv_decode_gemv3: even row counts and K % 8 == 0 required");
+    DecodeGemvArgs a{};
+    a.W = (const bf16_t*)Wa; a.Wb = (const bf16_t*)Wb; a.Wc = (const bf16_t*)Wc; a.x = (const bf16_t*)x;
+    a.y = (bf16_t*)ya; a.yb = (bf16_t*)yb; a.yc = (bf16_t*)yc; a.N = Na; a.Nb = Nb; a.Nc = Nc; a.K = K;
+    MERV_HIP(launch_decode_gemv(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_decode_rope_cache(const void* q, const void* k, const void* v, void* q_out, void* k_cache, void* v_cache,
+                                      const void* cos_t, const void* sin_t, const int64_t* pos, int32_t H, int32_t Hkv, int32_t hd,
+                                      int32_t max_len, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && q_out && k_cache && v_cache && cos_t && sin_t && pos, "merv_decode_rope_cache: null argument");
+    MERV_CHECK(H > 0 && Hkv > 0 && hd > 0 && hd % 2 == 0 && max_len > 0, "merv_decode_rope_cache: bad geometry");
+    DecodeRopeArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                     (const bf16_t*)cos_t, (const bf16_t*)sin_t, (const long*)pos, H, Hkv, hd, max_len};
+    MERV_HIP(launch_decode_rope_cache(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" size_t merv_decode_attention_workspace_floats(int32_t H, int32_t nsplit) {
+    if (H <= 0 || nsplit <= 0) return 0;
+    return (size_t)H * nsplit * (128 + 2);
+}
+
+extern "C" int merv_decode_attention(const void* q, const void* k_cache, const void* v_cache, void* out, float* ws, const int64_t* pos,
+                                     int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, int32_t nsplit, float scale, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k_cache && v_cache && out && ws && pos, "merv_decode_attention: null argument");
+    MERV_CHECK(hd == 128, "merv_decode_attention: head_dim must be 128 (Llama-2 / Mistral 7B and 13B)");
+    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attention: bad geometry");
+    DecodeAttnArgs a{(const bf16_t*)q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, (bf16_t*)out, ws, (const long*)pos, H, Hkv, hd,
+                     max_len, nsplit, scale};
+    MERV_HIP(launch_decode_attention(a, (hipStream_t)stream_));
+    return 0;
+}

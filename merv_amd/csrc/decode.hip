@@ -4,7 +4,7 @@
 // The north_star keeps the LLM *prefill* on PyTorch-ROCm. A decode step, though, is ~1100 tiny PyTorch kernels per token
 // (RMSNorm = 8 launches, rotary embedding = 10, ...): measured on MI355X, 6.1 of the 10.4 ms of a graph-replayed
 // Llama-2-7B step are those launches, 4.7 ms the library's M = 1 GEMMs at 2.4-3.4 TB/s (tools/probes/decode_breakdown.py).
-// These kernels are the step as 11 launches per layer, every one a pure HBM stream:
+// These kernels are the step as 9 launches per layer, every one a pure HBM stream:
 //
 //   rmsnorm_kernel         y = w * bf16(x * rsqrt(mean(x^2) + eps))                    (LlamaRMSNorm.forward)
 //   gemv_kernel            y = bf16(W x) [+ residual]      W [N, K] bf16 streamed once (nn.Linear, M = 1)
@@ -68,8 +68,16 @@ constexpr int GEMV_WAVES = 4;  // waves per block
 template <int NW_MATS>  // 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x)
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int n0 = (blockIdx.x * GEMV_WAVES + wave) * GEMV_ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
+    int n0 = (blockIdx.x * GEMV_WAVES + wave) * GEMV_ROWS;
+    // several matrices in one launch (q / k / v): a wave's rows lie in ONE of them (row counts are multiples of GEMV_ROWS)
+    if constexpr (NW_MATS == 1) {
+        if (n0 >= p.N && p.Nb > 0) {
+            n0 -= p.N;
+            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; }
+            else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; }
+        }
+    }
     if (n0 >= p.N) return;
     const int nchunk = p.K >> 3;
     float acc[NW_MATS][GEMV_ROWS];
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(DecodeRopeArgs p) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int head = i / hd, d = i - head * hd;
         if (head < p.H + p.Hkv) {
-            bf16_t* vec = head < p.H ? p.q + head * hd : p.k + (head - p.H) * hd;
+            const bf16_t* vec = head < p.H ? p.q + head * hd : p.k + (head - p.H) * hd;
             const float a = bf2f(vec[d]);
             const float b = d < half ? -bf2f(vec[d + half]) : bf2f(vec[d - half]);  // rotate_half
             const float r = round_bf(round_bf(a * bf2f(cs[d])) + round_bf(b * bf2f(sn[d])));
@@ -263,7 +271,12 @@ hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
 hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     if (a.N <= 0 || a.K <= 0 || a.K % 8 != 0) return hipErrorInvalidValue;
     const int rows_per_block = GEMV_ROWS * GEMV_WAVES;
-    dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
+    if (a.Nb > 0 || a.Nc > 0) {
+        if (a.W2 || a.res || a.y32 || a.N % GEMV_ROWS || a.Nb % GEMV_ROWS || a.Nc % GEMV_ROWS || (a.Nb > 0 && (!a.Wb || !a.yb)) ||
+            (a.Nc > 0 && (!a.Wc || !a.yc || a.Nb <= 0)))
+            return hipErrorInvalidValue;
+    }
+    dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
     if (a.W2) hipLaunchKernelGGL(gemv_kernel<2>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
     else hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
     return hipGetLastError();

@@ -246,4 +246,59 @@ hipError_t launch_pil_resize_normalize(const uint8_t* frames, int T, int H, int 
 hipError_t launch_languagebind_transform(const uint8_t* frames, int T, int H, int W, int S, int flip, const float* mean, const float* sd,
                                          void* out_pix, int out_bf16, hipStream_t s);
 
+
+// ---- batch-1 token decode of the LLM hand-off (decode.hip; row f-3) ----
+struct DecodeRmsArgs {   // LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps))
+    const bf16_t* x;     // [rows, D]
+    const bf16_t* w;     // [D]
+    bf16_t* y;           // [rows, D]
+    int rows, D;
+    float eps;
+};
+hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s);
+
+struct DecodeGemvArgs {  // y = bf16(W x) (+ res), or with W2: y = silu(bf16(W x)) * bf16(W2 x); x [K], y [N]
+    // up to three matrices that share x in ONE launch (q / k / v projections): rows [0, N) belong to W / y, rows
+    // [N, N + Nb) to Wb / yb, rows [N + Nb, N + Nb + Nc) to Wc / yc (Nb = Nc = 0: a single matrix)
+    const bf16_t* Wb;
+    const bf16_t* Wc;
+    bf16_t* yb;
+    bf16_t* yc;
+    int Nb, Nc;
+    const bf16_t* W;     // [N, K] (nn.Linear layout)
+    const bf16_t* W2;    // [N, K] or nullptr
+    const bf16_t* x;     // [K]
+    const bf16_t* res;   // [N] or nullptr (may alias y)
+    bf16_t* y;           // [N] bf16 output ...
+    float* y32;          // ... or, when set, fp32 output (logits)
+    int N, K;
+};
+hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s);
+
+struct DecodeRopeArgs {  // rotary embedding of q / k at *pos, cache[pos] <- k, v
+    const bf16_t* q;     // [H * hd]
+    const bf16_t* k;     // [Hkv * hd]
+    const bf16_t* v;     // [Hkv * hd]
+    bf16_t* q_out;       // [H * hd] rotated query
+    bf16_t* k_cache;     // [Hkv, max_len, hd]
+    bf16_t* v_cache;
+    const bf16_t* cos;   // [max_len, hd]
+    const bf16_t* sin;
+    const long* pos;     // device int64: position of the token being decoded
+    int H, Hkv, hd, max_len;
+};
+hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s);
+
+struct DecodeAttnArgs {  // softmax(q K^T * scale) V over cache positions 0 .. *pos, one query per head; hd == 128
+    const bf16_t* q;     // [H * hd]
+    const bf16_t* k_cache;
+    const bf16_t* v_cache;
+    bf16_t* out;         // [H * hd]
+    float* ws;           // [H][nsplit][hd + 2] partial (o, m, l)
+    const long* pos;
+    int H, Hkv, hd, max_len, nsplit;
+    float scale;
+};
+hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
+
 }  // namespace merv

@@ -90,7 +90,8 @@ class LlamaBackbone:
     def generate_from_embeds(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 32, do_sample: bool = False,
                              temperature: float = 1.0, eos_token_id: Optional[int] = None,
                              generator: Optional[torch.Generator] = None, use_graph: bool = True, top_k: int = 0,
-                             top_p: float = 1.0, repetition_penalty: float = 1.0, min_new_tokens: int = 0) -> torch.LongTensor:
+                             top_p: float = 1.0, repetition_penalty: float = 1.0, min_new_tokens: int = 0,
+                             use_hip_decode: bool = True) -> torch.LongTensor:
         """Prefill on `inputs_embeds` [B, S, D] (merv.py:723-734), then decode token by token on the KV cache
         (merv.py:524-538). Returns the new token ids [B, <= max_new_tokens]. Decoding controls are the subset of HF
         `generate` kwargs the reference's scripts pass through (merv.py:818-825): greedy or sampling with `temperature`,
@@ -100,12 +101,13 @@ class LlamaBackbone:
             # static-cache prefill + hipGraph-replayed decode steps (StaticDecoder above)
             need = inputs_embeds.shape[1] + max_new_tokens + 1
             bucket = min((need + 255) // 256 * 256, self.config.max_position_embeddings)  # cache length, reused across calls
-            key = (bucket, inputs_embeds.shape[0])
+            key = (bucket, inputs_embeds.shape[0], bool(use_hip_decode))
             if not hasattr(self, "_decoders"):
                 self._decoders = {}
             if key not in self._decoders:
                 self._decoders.clear()  # one static cache at a time (a 7B model's is ~0.5 GB per 1024 positions)
-                self._decoders[key] = StaticDecoder(self.llm, bucket, inputs_embeds.shape[0])
+                cls = HipDecoder if (use_hip_decode and HipDecoder.supports(self.llm, inputs_embeds.shape[0])) else StaticDecoder
+                self._decoders[key] = cls(self.llm, bucket, inputs_embeds.shape[0])
             dec = self._decoders[key]
             logits = dec.prefill(inputs_embeds)
             step = lambda tok: dec.decode(tok, use_graph=True)
@@ -269,6 +271,67 @@ class StaticDecoder:
         out = self._step()
         self.pos += 1
         return out
+
+
+class HipDecoder(StaticDecoder):
+    """The batch-1 decode step of `StaticDecoder` on libmerv_hip.so's decode kernels (csrc/decode.hip): 9 launches per layer
+    -- RMSNorm, the q / k / v projections as one GEMV launch, rotary + cache update, split attention + merge, o-projection with the residual, RMSNorm, the
+    gated MLP as one GEMV pair with silu * up fused, down-projection with the residual -- instead of ~35 PyTorch ones, each a
+    pure HBM stream (weights read once, non-temporal). Same parameters (the HF module's, no copies), same static cache and
+    rotary tables, same rounding points as the bf16 module; prefill stays on PyTorch-ROCm (north_star). Measured on MI355X
+    with Llama-2-7B geometry: see DESIGN.md section 6 (e2e)."""
+
+    NSPLIT = 8  # position ranges per head in decode attention: 32 heads x 8 = one block per CU
+
+    @staticmethod
+    def supports(hf_model, batch: int) -> bool:
+        cfg = hf_model.config
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        p = next(hf_model.parameters())
+        lyr = hf_model.model.layers[0]
+        return (batch == 1 and hd == 128 and p.is_cuda and p.dtype == torch.bfloat16 and lyr.self_attn.q_proj.bias is None
+                and lyr.self_attn.o_proj.bias is None and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0)
+
+    def __init__(self, hf_model, max_len: int, batch: int = 1) -> None:
+        super().__init__(hf_model, max_len, batch)
+        from . import _lib
+        self.lib = _lib.load()
+        cfg = self.cfg
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        mk = lambda n, dt=self.dt: torch.empty(n, dtype=dt, device=self.dev)
+        self.x, self.h, self.ao, self.mid = mk(D), mk(D), mk(self.H * self.hd), mk(I)
+        self.q, self.q2, self.k, self.v = mk(self.H * self.hd), mk(self.H * self.hd), mk(self.Hkv * self.hd), mk(self.Hkv * self.hd)
+        self.ws = mk(self.lib.merv_decode_attention_workspace_floats(self.H, self.NSPLIT), torch.float32)
+        self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
+
+    def _step(self):
+        from ._lib import check, ptr
+        lib, m = self.lib, self.m
+        with torch.cuda.device(self.dev):
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            D, I, H, Hkv, hd = self.cfg.hidden_size, self.cfg.intermediate_size, self.H, self.Hkv, self.hd
+            self.x.copy_(m.model.embed_tokens(self.tok).reshape(-1))
+            x, h, pos = ptr(self.x), ptr(self.h), ptr(self.pos)
+
+            def gemv(W, W2, xin, res, y, N, K, y32=0):
+                check(lib.merv_decode_gemv(ptr(W), 0 if W2 is None else ptr(W2), xin, res, y, y32, N, K, st), "merv_decode_gemv")
+
+            for li, lyr in enumerate(m.model.layers):
+                a, mlp = lyr.self_attn, lyr.mlp
+                check(lib.merv_decode_rmsnorm(x, ptr(lyr.input_layernorm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
+                check(lib.merv_decode_gemv3(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), h, ptr(self.q), ptr(self.k),
+                                            ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, st), "merv_decode_gemv3")
+                check(lib.merv_decode_rope_cache(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]),
+                                                 ptr(self.cos), ptr(self.sin), pos, H, Hkv, hd, self.max_len, st), "merv_decode_rope_cache")
+                check(lib.merv_decode_attention(ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]), ptr(self.ao), ptr(self.ws), pos, H, Hkv,
+                                                hd, self.max_len, self.NSPLIT, hd**-0.5, st), "merv_decode_attention")
+                gemv(a.o_proj.weight, None, ptr(self.ao), x, x, D, H * hd)  # x += o_proj(attn)
+                check(lib.merv_decode_rmsnorm(x, ptr(lyr.post_attention_layernorm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
+                gemv(mlp.gate_proj.weight, mlp.up_proj.weight, h, 0, ptr(self.mid), I, D)  # silu(gate) * up
+                gemv(mlp.down_proj.weight, None, ptr(self.mid), x, x, D, I)  # x += down_proj(...)
+            check(lib.merv_decode_rmsnorm(x, ptr(m.model.norm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
+            gemv(m.lm_head.weight, None, h, 0, 0, self.cfg.vocab_size, D, y32=ptr(self.logits32))
+        return self.logits32
 
 
 # === Language Model Registry (materialize.py:76-101, llama2.py:24-51): ids wired on this path -> (family, geometry) ===
