@@ -12,7 +12,8 @@ frames [16,16,32,16], bf16) on N MI355X. Contract: see the task statement; ONE J
                  projector's output and the fused [1,1024,4096] tokens (N = 1 only)
   cpu_baseline = the wall time of that same oracle run on this host's cores (no extrapolation)
   e2e          = BASELINE.json's secondary metric: quick_start-shaped generate() (GPU frame transforms -> visual path ->
-                 Llama-2-7B-geometry prefill -> graph-replayed greedy decode), generated tokens / s (N = 1 only)
+                 Llama-2-7B-geometry prefill on PyTorch-ROCm -> greedy decode on the HIP decode kernels), generated tokens / s
+                 (N = 1 only)
   multi_gpu    = N > 1: besides the data-parallel headline, the (encoder, video, frame-range) unit placement with both RCCL
                  exchanges timed in the same process group (BASELINE.json configs[2])
 """
@@ -158,8 +159,10 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
     torch.cuda.synchronize(); t_pre = time.perf_counter() - t0
     m.encode(vv); torch.cuda.synchronize()
     t0 = time.perf_counter(); m.encode(vv); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
-    res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init (PyTorch-ROCm SDPA prefill, "
-                   "hipGraph-replayed static-cache decode)",
+    dec = next(iter(llm._decoders.values()))
+    res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill on PyTorch-ROCm (SDPA), "
+                   f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 9 launches per layer" if type(dec).__name__ == "HipDecoder"
+                                                                else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
            "new_tokens": int(out.shape[1]), "total_s": round(t, 4), "generated_tok_per_s": round(out.shape[1] / t, 2),
            "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": TOKENS_PER_VIDEO + len(prompt)}
     del m, llm
