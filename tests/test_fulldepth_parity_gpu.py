@@ -16,10 +16,13 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
-def test_full_depth_full_width_parity_vs_oracle(dev):
+@pytest.mark.parametrize("batch", [1, 8])
+def test_full_depth_full_width_parity_vs_oracle(dev, batch):
+    """batch = 8 is the bench's own step: the compared video is the last of the batch, whose rows are the ones every GEMM's
+    second launch (the rows behind the round-filling split) computes."""
     import bench
     specs, _, path, extras = bench.build_models(dev, concurrent=True, want_ref=True)
-    par, cpu = bench.parity_and_cpu_baseline(path, specs, extras["ref"], dev)
+    par, cpu = bench.parity_and_cpu_baseline(path, specs, extras["ref"], dev, batch=batch)
     print("full-depth parity:", par)
     print("oracle:", cpu["sample"])
     for name, v in par["encoders"].items():
