@@ -287,11 +287,13 @@ int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flo
 /*
  * Batch-1 token decode of the LLM hand-off: the per-token forward HF GenerationMixin runs for
  * the reference's generate() (merv/models/vidlms/merv.py:818-825 -> LlamaForCausalLM.forward with a KV cache). The prefill
- * stays on PyTorch-ROCm (north_star); a decode step is 9 launches per layer of these HBM-bound kernels instead of ~35
+ * stays on PyTorch-ROCm (north_star); a decode step is 7 launches per layer of these HBM-bound kernels instead of ~35
  * PyTorch ones. bf16 tensors, fp32 accumulation, bf16 rounding wherever the module materialises a bf16 tensor.
  *  merv_decode_rmsnorm     LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, y [rows, D], w [D]
  *  merv_decode_gemv        nn.Linear at M = 1: y[N] = bf16(W[N,K] x[K]) (+ res[N]); with W2: y = silu(bf16(W x)) * bf16(W2 x)
- *                          (LlamaMLP's act_fn(gate_proj(x)) * up_proj(x)); y32 != NULL: fp32 output instead (logits)
+ *                          (LlamaMLP's act_fn(gate_proj(x)) * up_proj(x)); y32 != NULL: fp32 output instead (logits);
+ *                          norm_w != NULL: the RMSNorm of the input fused in (x is the raw residual stream; bit-identical to
+ *                          merv_decode_rmsnorm followed by the plain call)
  *  merv_decode_rope_cache  apply_rotary_pos_emb at position *pos (device int64) on q [H*hd] -> q_out and k [Hkv*hd] -> k_cache[:, *pos],
  *                          v -> v_cache[:, *pos]; caches [Hkv, max_len, hd], cos / sin tables [max_len, hd] bf16
  *  merv_decode_attention   out[H*hd] = softmax(q K^T * scale) V over cache positions 0..*pos (GQA: kv head = h / (H/Hkv)),
@@ -300,13 +302,13 @@ int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flo
  */
 int merv_decode_rmsnorm(const void *x, const void *w, void *y, int32_t rows, int32_t D, float eps, void *stream);
 int merv_decode_gemv(const void *W, const void *W2, const void *x, const void *res, void *y, float *y32, int32_t N, int32_t K,
-                     void *stream);
+                     const void *norm_w, float norm_eps, void *stream);
 int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_out, void *k_cache, void *v_cache,
                            const void *cos_t, const void *sin_t, const int64_t *pos, int32_t H, int32_t Hkv, int32_t hd,
                            int32_t max_len, void *stream);
 /* three projections of the same input in one launch (q_proj / k_proj / v_proj): y_i[N_i] = bf16(W_i[N_i,K] x[K]) */
 int merv_decode_gemv3(const void *Wa, const void *Wb, const void *Wc, const void *x, void *ya, void *yb, void *yc,
-                      int32_t Na, int32_t Nb, int32_t Nc, int32_t K, void *stream);
+                      int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void *norm_w, float norm_eps, void *stream);
 size_t merv_decode_attention_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention(const void *q, const void *k_cache, const void *v_cache, void *out, float *ws, const int64_t *pos,
                           int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, int32_t nsplit, float scale, void *stream);

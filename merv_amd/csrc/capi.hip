@@ -769,7 +769,7 @@ extern "C" int merv_decode_rmsnorm(const void* x, const void* w, void* y, int32_
 }
 
 extern "C" int merv_decode_gemv(const void* W, const void* W2, const void* x, const void* res, void* y, float* y32, int32_t N,
-                                int32_t K, void* stream_) {
+                                int32_t K, const void* norm_w, float norm_eps, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(W && x && (y || y32), "merv_decode_gemv: null argument");
     MERV_CHECK(N > 0 && K > 0 && K % 8 == 0, "merv_decode_gemv: N > 0 and K % 8 == 0 required");
@@ -777,13 +777,13 @@ extern "C" int merv_decode_gemv(const void* W, const void* W2, const void* x, co
     MERV_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && (!W2 || ((uintptr_t)W2 & 15) == 0), "merv_decode_gemv: 16-byte alignment required");
     DecodeGemvArgs a{};
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.x = (const bf16_t*)x; a.res = (const bf16_t*)res; a.y = (bf16_t*)y; a.y32 = y32;
-    a.N = N; a.K = K;
+    a.N = N; a.K = K; a.norm_w = (const bf16_t*)norm_w; a.norm_eps = norm_eps;
     MERV_HIP(launch_decode_gemv(a, (hipStream_t)stream_));
     return 0;
 }
 
 extern "C" int merv_decode_gemv3(const void* Wa, const void* Wb, const void* Wc, const void* x, void* ya, void* yb, void* yc,
-                                 int32_t Na, int32_t Nb, int32_t Nc, int32_t K, void* stream_) {
+                                 int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void* norm_w, float norm_eps, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(Wa && Wb && Wc && x && ya && yb && yc, "merv_decode_gemv3: null argument");
     MERV_CHECK(Na > 0 && Nb > 0 && Nc > 0 && Na % 2 == 0 && Nb % 2 == 0 && Nc % 2 == 0 && K > 0 && K % 8 == 0,
@@ -791,6 +791,7 @@ extern "C" int merv_decode_gemv3(const void* Wa, const void* Wb, const void* Wc,
     DecodeGemvArgs a{};
     a.W = (const bf16_t*)Wa; a.Wb = (const bf16_t*)Wb; a.Wc = (const bf16_t*)Wc; a.x = (const bf16_t*)x;
     a.y = (bf16_t*)ya; a.yb = (bf16_t*)yb; a.yc = (bf16_t*)yc; a.N = Na; a.Nb = Nb; a.Nc = Nc; a.K = K;
+    a.norm_w = (const bf16_t*)norm_w; a.norm_eps = norm_eps;
     MERV_HIP(launch_decode_gemv(a, (hipStream_t)stream_));
     return 0;
 }

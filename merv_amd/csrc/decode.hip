@@ -4,7 +4,7 @@
 // The north_star keeps the LLM *prefill* on PyTorch-ROCm. A decode step, though, is ~1100 tiny PyTorch kernels per token
 // (RMSNorm = 8 launches, rotary embedding = 10, ...): measured on MI355X, 6.1 of the 10.4 ms of a graph-replayed
 // Llama-2-7B step are those launches, 4.7 ms the library's M = 1 GEMMs at 2.4-3.4 TB/s (tools/probes/decode_breakdown.py).
-// These kernels are the step as 9 launches per layer, every one a pure HBM stream:
+// These kernels are the step as 7 launches per layer, every one a pure HBM stream:
 //
 //   rmsnorm_kernel         y = w * bf16(x * rsqrt(mean(x^2) + eps))                    (LlamaRMSNorm.forward)
 //   gemv_kernel            y = bf16(W x) [+ residual]      W [N, K] bf16 streamed once (nn.Linear, M = 1)
@@ -92,11 +92,34 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
         wrow[0][r] = p.W + (size_t)n * p.K;
         if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
     }
-    // 4 chunks per lane per trip: 4 x ROWS x NW_MATS weight loads of 16 B in flight per lane before the first use
-    constexpr int UN = 4;
+    // fused RMSNorm: the wave reduces mean(x^2) over the whole input once (8 KB, L2-resident; its latency overlaps the first
+    // weight loads issued below), then normalises each chunk it multiplies
+    float rstd = 0.f;
+    if (p.norm_w) {
+        float ss = 0.f;
+        for (int c = lane; c < nchunk; c += 64) {
+            float f[8];
+            unpack8f(*(const u32x4*)(p.x + c * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+        }
+        rstd = rsqrtf(wave_sum64(ss) / (float)p.K + p.norm_eps);
+    }
+    auto norm8 = [&](const u32x4& xraw, const u32x4& wraw, float (&xf)[8]) {
+        unpack8f(xraw, xf);
+        if (p.norm_w) {
+            float wn[8];
+            unpack8f(wraw, wn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = round_bf(wn[j] * round_bf(xf[j] * rstd));
+        }
+    };
+    // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and the x / norm-weight chunks they meet) are in
+    // flight per lane before the first use
+    constexpr int UN = 4;  // measured on MI355X (step time with Llama-2-7B geometry): UN x ROWS = 4 x 2: 3.36 ms; 2 x 2 3.36; 8 x 2 3.59; 4 x 4 3.53; 4 x 1 3.44; 8 x 1 3.61
     int c = lane;
     for (; c + 64 * (UN - 1) < nchunk; c += 64 * UN) {
-        u32x4 xv[UN], wv[NW_MATS][GEMV_ROWS][UN];
+        u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
 #pragma unroll
@@ -105,11 +128,12 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
                 for (int r = 0; r < GEMV_ROWS; ++r)
                     wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + (c + 64 * u) * 8));
             xv[u] = *(const u32x4*)(p.x + (c + 64 * u) * 8);
+            nv[u] = p.norm_w ? *(const u32x4*)(p.norm_w + (c + 64 * u) * 8) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             float xf[8];
-            unpack8f(xv[u], xf);
+            norm8(xv[u], nv[u], xf);
 #pragma unroll
             for (int m = 0; m < NW_MATS; ++m)
 #pragma unroll
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     }
     for (; c < nchunk; c += 64) {
         float xf[8];
-        unpack8f(*(const u32x4*)(p.x + c * 8), xf);
+        norm8(*(const u32x4*)(p.x + c * 8), p.norm_w ? *(const u32x4*)(p.norm_w + c * 8) : u32x4{0u, 0u, 0u, 0u}, xf);
 #pragma unroll
         for (int m = 0; m < NW_MATS; ++m)
 #pragma unroll

@@ -272,6 +272,11 @@ struct DecodeGemvArgs {  // y = bf16(W x) (+ res), or with W2: y = silu(bf16(W x
     bf16_t* y;           // [N] bf16 output ...
     float* y32;          // ... or, when set, fp32 output (logits)
     int N, K;
+    // RMSNorm of the input fused in (input_layernorm -> q/k/v, post_attention_layernorm -> gate/up, norm -> lm_head): x is the
+    // raw residual stream and every wave normalises the chunks it multiplies, w * bf16(x * rsqrt(mean(x^2) + eps)) -- the
+    // same two roundings as the stand-alone kernel, so the result is bit-identical to rmsnorm + gemv
+    const bf16_t* norm_w;  // [K] or nullptr
+    float norm_eps;
 };
 hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s);
 

@@ -274,9 +274,9 @@ class StaticDecoder:
 
 
 class HipDecoder(StaticDecoder):
-    """The batch-1 decode step of `StaticDecoder` on libmerv_hip.so's decode kernels (csrc/decode.hip): 9 launches per layer
-    -- RMSNorm, the q / k / v projections as one GEMV launch, rotary + cache update, split attention + merge, o-projection with the residual, RMSNorm, the
-    gated MLP as one GEMV pair with silu * up fused, down-projection with the residual -- instead of ~35 PyTorch ones, each a
+    """The batch-1 decode step of `StaticDecoder` on libmerv_hip.so's decode kernels (csrc/decode.hip): 7 launches per layer
+    -- the q / k / v projections as one GEMV launch with the input RMSNorm fused in, rotary + cache update, split attention + merge, o-projection with the residual, the
+    gated MLP as one GEMV pair with its RMSNorm and silu * up fused, down-projection with the residual -- instead of ~35 PyTorch ones, each a
     pure HBM stream (weights read once, non-temporal). Same parameters (the HF module's, no copies), same static cache and
     rotary tables, same rounding points as the bf16 module; prefill stays on PyTorch-ROCm (north_star). Measured on MI355X
     with Llama-2-7B geometry: see DESIGN.md section 6 (e2e)."""
@@ -313,24 +313,24 @@ class HipDecoder(StaticDecoder):
             self.x.copy_(m.model.embed_tokens(self.tok).reshape(-1))
             x, h, pos = ptr(self.x), ptr(self.h), ptr(self.pos)
 
-            def gemv(W, W2, xin, res, y, N, K, y32=0):
-                check(lib.merv_decode_gemv(ptr(W), 0 if W2 is None else ptr(W2), xin, res, y, y32, N, K, st), "merv_decode_gemv")
+            def gemv(W, W2, xin, res, y, N, K, y32=0, norm=None):
+                check(lib.merv_decode_gemv(ptr(W), 0 if W2 is None else ptr(W2), xin, res, y, y32, N, K,
+                                           0 if norm is None else ptr(norm), self.eps, st), "merv_decode_gemv")
 
             for li, lyr in enumerate(m.model.layers):
                 a, mlp = lyr.self_attn, lyr.mlp
-                check(lib.merv_decode_rmsnorm(x, ptr(lyr.input_layernorm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
-                check(lib.merv_decode_gemv3(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), h, ptr(self.q), ptr(self.k),
-                                            ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, st), "merv_decode_gemv3")
+                # input_layernorm fused into the q / k / v launch, post_attention_layernorm into the gate / up launch
+                check(lib.merv_decode_gemv3(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), x, ptr(self.q), ptr(self.k),
+                                            ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps, st),
+                      "merv_decode_gemv3")
                 check(lib.merv_decode_rope_cache(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]),
                                                  ptr(self.cos), ptr(self.sin), pos, H, Hkv, hd, self.max_len, st), "merv_decode_rope_cache")
                 check(lib.merv_decode_attention(ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]), ptr(self.ao), ptr(self.ws), pos, H, Hkv,
                                                 hd, self.max_len, self.NSPLIT, hd**-0.5, st), "merv_decode_attention")
                 gemv(a.o_proj.weight, None, ptr(self.ao), x, x, D, H * hd)  # x += o_proj(attn)
-                check(lib.merv_decode_rmsnorm(x, ptr(lyr.post_attention_layernorm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
-                gemv(mlp.gate_proj.weight, mlp.up_proj.weight, h, 0, ptr(self.mid), I, D)  # silu(gate) * up
+                gemv(mlp.gate_proj.weight, mlp.up_proj.weight, x, 0, ptr(self.mid), I, D, norm=lyr.post_attention_layernorm.weight)
                 gemv(mlp.down_proj.weight, None, ptr(self.mid), x, x, D, I)  # x += down_proj(...)
-            check(lib.merv_decode_rmsnorm(x, ptr(m.model.norm.weight), h, 1, D, self.eps, st), "merv_decode_rmsnorm")
-            gemv(m.lm_head.weight, None, h, 0, 0, self.cfg.vocab_size, D, y32=ptr(self.logits32))
+            gemv(m.lm_head.weight, None, x, 0, 0, self.cfg.vocab_size, D, y32=ptr(self.logits32), norm=m.model.norm.weight)
         return self.logits32
 
 

@@ -42,19 +42,29 @@ def test_gemv_forms(dev, N, K):
     res = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
     lin = (W.float() @ x.float())
     y = torch.empty(N, dtype=torch.bfloat16, device=dev)
-    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, ptr(y), 0, N, K, _st(dev)), "gemv")
+    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, ptr(y), 0, N, K, 0, 0.0, _st(dev)), "gemv")
     assert rel_l2(y, lin) < 4e-3
     y32 = torch.empty(N, dtype=torch.float32, device=dev)
-    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, 0, ptr(y32), N, K, _st(dev)), "gemv32")
+    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, 0, ptr(y32), N, K, 0, 0.0, _st(dev)), "gemv32")
     assert torch.equal(y32, y.float())  # logits = .float() of the bf16 linear output
     r = res.clone()
-    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), ptr(r), ptr(r), 0, N, K, _st(dev)), "gemv+res")  # in place: x += linear
+    check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), ptr(r), ptr(r), 0, N, K, 0, 0.0, _st(dev)), "gemv+res")  # in place: x += linear
     assert rel_l2(r, res.float() + lin.to(torch.bfloat16).float()) < 4e-3
-    check(lib.merv_decode_gemv(ptr(W), ptr(W2), ptr(x), 0, ptr(y), 0, N, K, _st(dev)), "gated")
+    check(lib.merv_decode_gemv(ptr(W), ptr(W2), ptr(x), 0, ptr(y), 0, N, K, 0, 0.0, _st(dev)), "gated")
     ref = F.silu(lin.to(torch.bfloat16)) * (W2.float() @ x.float()).to(torch.bfloat16)  # act_fn(gate_proj(x)) * up_proj(x)
     assert rel_l2(y, ref) < 8e-3
     with pytest.raises(ValueError):
-        check(lib.merv_decode_gemv(ptr(W), ptr(W2), ptr(x), ptr(res), ptr(y), 0, N, K, _st(dev)), "gated+res")
+        check(lib.merv_decode_gemv(ptr(W), ptr(W2), ptr(x), ptr(res), ptr(y), 0, N, K, 0, 0.0, _st(dev)), "gated+res")
+    # RMSNorm fused into the launch == merv_decode_rmsnorm followed by the plain launch, bit for bit (plain and gated form)
+    wn = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    xr = (x.float() * 3).to(torch.bfloat16)
+    hn = torch.empty_like(xr)
+    check(lib.merv_decode_rmsnorm(ptr(xr), ptr(wn), ptr(hn), 1, K, 1e-5, _st(dev)), "rms")
+    two, fused = torch.empty_like(y), torch.empty_like(y)
+    for W2p in (0, ptr(W2)):
+        check(lib.merv_decode_gemv(ptr(W), W2p, ptr(hn), 0, ptr(two), 0, N, K, 0, 0.0, _st(dev)), "gemv")
+        check(lib.merv_decode_gemv(ptr(W), W2p, ptr(xr), 0, ptr(fused), 0, N, K, ptr(wn), 1e-5, _st(dev)), "norm+gemv")
+        assert torch.equal(fused, two)
 
 
 def test_gemv3_equals_three_gemvs(dev):
@@ -67,10 +77,10 @@ def test_gemv3_equals_three_gemvs(dev):
     Ws = [(torch.randn(n, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev) for n in Ns]
     x = torch.randn(K, generator=g).to(torch.bfloat16).to(dev)
     ys = [torch.empty(n, dtype=torch.bfloat16, device=dev) for n in Ns]
-    check(lib.merv_decode_gemv3(ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(x), ptr(ys[0]), ptr(ys[1]), ptr(ys[2]), *Ns, K, _st(dev)), "gemv3")
+    check(lib.merv_decode_gemv3(ptr(Ws[0]), ptr(Ws[1]), ptr(Ws[2]), ptr(x), ptr(ys[0]), ptr(ys[1]), ptr(ys[2]), *Ns, K, 0, 0.0, _st(dev)), "gemv3")
     for W, y, n in zip(Ws, ys, Ns):
         one = torch.empty(n, dtype=torch.bfloat16, device=dev)
-        check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, ptr(one), 0, n, K, _st(dev)), "gemv")
+        check(lib.merv_decode_gemv(ptr(W), 0, ptr(x), 0, ptr(one), 0, n, K, 0, 0.0, _st(dev)), "gemv")
         assert torch.equal(y, one)
 
 

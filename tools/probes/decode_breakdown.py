@@ -98,7 +98,7 @@ for name, (n, k, gated) in {"hip q/k/v/o 4096x4096": (4096, 4096, False), "hip g
     st = torch.cuda.current_stream(dev).cuda_stream
 
     def call(i):
-        check(lib.merv_decode_gemv(ptr(ws[i]), ptr(ws[(i + 1) % 8]) if gated else 0, ptr(xin), 0, ptr(y), 0, n, k,
+        check(lib.merv_decode_gemv(ptr(ws[i]), ptr(ws[(i + 1) % 8]) if gated else 0, ptr(xin), 0, ptr(y), 0, n, k, 0, 0.0,
                                    torch.cuda.current_stream(dev).cuda_stream), "gemv")
     call(0); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
