@@ -67,10 +67,20 @@ MERV_DEVICE bf16x8 pack8(const f32x16& s, int base) {
 
 // V^T A-operand fragment for O^T[d-block db] over the 16 keys starting at key_base (tile-local).
 // Element j of lane (r = lane & 31, h = lane >> 5) must be V[key_base + 8*(j>>2) + 4*h + (j&3)][db*32 + r].
-template <bool VTR>
+// SWZ128 (resident image): V rows are 128 B, unpadded; the 64-byte halves of rows 2, 3 (mod 4) are swapped so that the four
+// rows a 32-lane half reads (4 rows x 64 B) cover the 256-byte bank row exactly once (tile bases are multiples of 16 rows).
+template <bool VTR, bool SWZ128 = false>
 MERV_DEVICE bf16x8 load_vt_frag(const char* v_lds, int key_base, int db, int lane, int vrow_bytes) {
     const int h = lane >> 5;
-    if constexpr (VTR) {
+    if constexpr (SWZ128) {
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+        const int half = db ^ ((q4 >> 1) & 1);
+        const char* a0 = v_lds + (key_base + 4 * h + q4) * 128 + half * 64 + 32 * ((lane >> 4) & 1) + 8 * p4;
+        const char* a1 = a0 + 8 * 128;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a1);
+        return join8(lo, hi);
+    } else if constexpr (VTR) {
         // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block; lane 4q+p supplies row q, cols 4p..4p+3;
         // lane i of the group receives column i of the 4 rows.
         const int q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -109,21 +119,29 @@ MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u3
 // t % NW multiplies them against key tile t right after its own two tiles (K / V of that tile are in LDS anyway), leaves
 // {partial O, max, sum} in LDS, and the partials are merged after the loop (flash-decoding style). Bit pattern of the
 // result differs from the single-pass order only by fp32 summation order.
+// RES = true (with XQ; L <= 264): ALL K / V rows of the (sequence, head) are brought into LDS once by LDS-DMA (source-side
+// swizzle, 66 one-KiB pieces over the four waves) and the key-tile loop has no barrier, no staging registers and no global
+// load: the waves drift freely (the wave that multiplies the extra rows in iteration t no longer holds the others at a
+// barrier), and the second block of the CU computes while this one waits for its single load phase. 78 KB per block: two
+// blocks per CU.
 constexpr int XQ_ROWS = 8, XQ_SLOTS = 5;
-template <bool VTR, int NW, int QPW, bool XQ = false>
+constexpr int RES_KROWS = 264, RES_VROWS = 272;  // K rows past 264 are read (and masked) from whatever follows; V rows must be finite
+template <bool VTR, int NW, int QPW, bool XQ = false, bool RES = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
+    static_assert(!RES || (VTR && XQ && NW * QPW * 32 == 256), "resident form: 4 x 2 block with the extra-row split only");
     constexpr int NT = NW * 64;
-    constexpr int V_BYTES = VTR ? 64 * VROW_TR : 64 * VT_ROW;
-    constexpr int VROWB = VTR ? VROW_TR : VT_ROW;
+    constexpr int V_BYTES = RES ? RES_VROWS * 128 : (VTR ? 64 * VROW_TR : 64 * VT_ROW);
+    constexpr int K_BYTES = RES ? RES_KROWS * KROW : 64 * KROW;
+    constexpr int VROWB = RES ? 128 : (VTR ? VROW_TR : VT_ROW);
     constexpr int KSTG = (512 + NT - 1) / NT;   // 16-byte chunks of a 64x64 bf16 tile per thread
     constexpr int PSTG = (256 + NT - 1) / NT;   // (key pair, chunk) items per thread for the transposing V path
     constexpr int OUT_BYTES = NW * 32 * 128;    // output staging (reuses the K/V region after the last tile)
-    constexpr int KV_BYTES = (64 * KROW + V_BYTES) > OUT_BYTES ? (64 * KROW + V_BYTES) : OUT_BYTES;
+    constexpr int KV_BYTES = (K_BYTES + V_BYTES) > OUT_BYTES ? (K_BYTES + V_BYTES) : OUT_BYTES;
     constexpr int XQ_BYTES = XQ ? XQ_SLOTS * XQ_ROWS * (HD + 4) * 4 : 0;  // per (slot, row): 64 partial outputs, max, two half sums
     constexpr int LDS_BYTES = KV_BYTES + XQ_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     char* k_lds = smem;
-    char* v_lds = smem + 64 * KROW;
+    char* v_lds = smem + K_BYTES;
     float* xq_lds = (float*)(smem + KV_BYTES);  // [slot][row][HD + 4]
 
     const int tid = threadIdx.x;
@@ -141,22 +159,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     MERV_STAMP(0);
 
     // Q^T B-operand fragments: element j of step s = Q[q][16 s + 8 h + j]
-    bf16x8 qf[QPW][4];
+    auto ld16 = [&](const bf16_t* ptr) { return *(const u32x4*)ptr; };
+    u32x4 qraw[QPW][4], qxraw[4];
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi) {
         const int q_row = q_base + qi * 32 + r;
         const int q_ld = q_row < L ? q_row : L - 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            qf[qi][s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+        for (int s = 0; s < 4; ++s) qraw[qi][s] = ld16(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
     }
-
     constexpr int XQ0 = NW * QPW * 32;  // first extra query row (XQ launches have one block per (sequence, head))
-    bf16x8 qx[4];
     if constexpr (XQ) {
         const int q_ld = XQ0 + r < L ? XQ0 + r : L - 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qx[s] = *(const bf16x8*)(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
+        for (int s = 0; s < 4; ++s) qxraw[s] = ld16(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
     }
 
     f32x16 oacc[QPW][2];
@@ -219,17 +235,82 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     };
 
     const int ntiles = (L + 63) / 64;
-    load_tile(0);
+    if constexpr (RES) {
+        // one LDS-DMA wave-instruction = 8 rows x 128 B = 1 KiB, lane-linear in LDS; the chunk swizzles of the readers are
+        // applied to the per-lane SOURCE address (cdna_hip_programming.md rule 21); rows past L re-read the last row
+        // Two load phases. First: key tiles 0 and 1 (next to the Q fragment loads above, whose first use makes hipcc wait
+        // vmcnt(0) anyway: with a register load in flight beside LDS-DMA it drains the whole queue, cdna_hip_programming.md
+        // section 5 "Three .s-level traps" (b)). Behind the barrier: the DMA of tiles 2 .. 4, which lands under the compute of
+        // tiles 0 and 1 and is waited for (vmcnt(0) + barrier) at the top of tile 2 -- no register load is in flight then, so the
+        // compiler inserts no wait of its own inside the loop.
+        const int rr = lane >> 3, pcnk = lane & 7;
+        // The DMA itself goes through inline asm (recipe of cdna_hip_programming.md section 5.7: M0 = wave-uniform LDS byte
+        // address, saved and restored inside the statement): hipcc tracks the builtin form as a pending LDS write and puts
+        // s_waitcnt vmcnt(0) in front of every later ds_read_b64_tr_b16 of the V image, which would drain the second phase at
+        // the first P.V product. The waits that order these DMAs against the LDS reads are the two explicit ones below.
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+        auto glds16 = [&](const bf16_t* gsrc, unsigned lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+        };
+        auto dma_k = [&](int pc) {
+            const int row = pc * 8 + rr;
+            const int grow = row < L ? row : L - 1;
+            glds16(kbase + (size_t)grow * ld + ((pcnk ^ kswz(row)) * 8), lds0 + pc * 1024);
+        };
+        auto dma_v = [&](int pc) {
+            const int row = pc * 8 + rr;
+            const int grow = row < L ? row : L - 1;
+            glds16(vbase + (size_t)grow * ld + ((pcnk ^ (((row >> 1) & 1) << 2)) * 8), lds0 + K_BYTES + pc * 1024);
+        };
+        static_assert(NW == 4 && RES_KROWS == 264 && RES_VROWS == 272, "piece schedule below is written for these sizes");
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {  // key tiles 0, 1: pieces 8 tq .. 8 tq + 7, two K and two V pieces per wave
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
+        }
+        // the BUILTIN form of the wait: hipcc's waitcnt pass sees it and retires the Q fragment loads in its own bookkeeping; after
+        // an asm wait it would still count them and stall their first uses on the second-phase DMAs it cannot see
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) alone (gfx9 encoding: expcnt = 7, lgkmcnt = 15 untouched)
+        __syncthreads();
+#pragma unroll
+        for (int tq = 2; tq < 4; ++tq) {
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
+        }
+        if (wv == 0) dma_k(32);          // K rows 256 .. 263
+        if (wv < 2) dma_v(32 + wv);      // V rows 256 .. 271
+    } else {
+        load_tile(0);
+    }
     MERV_STAMP(1);
+    bf16x8 qf[QPW][4], qx[4];
+#pragma unroll
+    for (int qi = 0; qi < QPW; ++qi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[qi][s] = __builtin_bit_cast(bf16x8, qraw[qi][s]);
+    if constexpr (XQ) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qx[s] = __builtin_bit_cast(bf16x8, qxraw[s]);
+    }
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * 64;
-        __syncthreads();  // previous tile's LDS reads are done
-        MERV_STAMP(2 + 4 * t);
-        write_tile();
-        MERV_STAMP(3 + 4 * t);
-        __syncthreads();
-        MERV_STAMP(4 + 4 * t);
-        if (t + 1 < ntiles) load_tile(kv0 + 64);
+        if constexpr (!RES) {
+            __syncthreads();  // previous tile's LDS reads are done
+            MERV_STAMP(2 + 4 * t);
+            write_tile();
+            MERV_STAMP(3 + 4 * t);
+            __syncthreads();
+            MERV_STAMP(4 + 4 * t);
+            if (t + 1 < ntiles) load_tile(kv0 + 64);
+        }
+        if constexpr (RES) {
+            if (t == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // key tiles 2 .. 4 have landed (every wave's share)
+        }
+        const char* k_t = RES ? k_lds + kv0 * KROW : k_lds;  // this key tile's rows
+        const char* v_t = RES ? v_lds + kv0 * 128 : v_lds;
         const bool tail = kv0 + 64 > L;
         // 257 = 4 * 64 + 1 and 3137 = 49 * 64 + 1: in the last tile of those sequences keys 32..63 are all padding;
         // their score MFMAs, exponentials and P.V MFMAs are skipped (wave-uniform)
@@ -245,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             for (int kb = 0; kb < 2; ++kb) {
                 if (kb == 1 && !both_halves) continue;
                 const int key = kb * 32 + r;
-                const char* krow = k_lds + key * KROW;
+                const char* krow = k_t + key * KROW;
                 const int sw = kswz(key);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sa[kb][i] = 0.f;
@@ -310,11 +391,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 pf = pack8(sa[kb], 8 * s2);
                     const int key_base = kb * 32 + 16 * s2;
+                    if constexpr (RES) { if (kv0 + key_base >= L) continue; }  // all 16 keys are padding (P = 0) and their V rows are not resident
+                    const bf16x8 pf = pack8(sa[kb], 8 * s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        const bf16x8 vf = load_vt_frag<VTR>(v_lds, key_base, db, lane, VROWB);
+                        const bf16x8 vf = load_vt_frag<VTR, RES>(v_t, key_base, db, lane, VROWB);
                         oacc[qi][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[qi][db], 0, 0, 0);
                     }
                 }
@@ -360,10 +442,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     if (kb == 1 && !both_halves) continue;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
+                        if constexpr (RES) { if (kv0 + kb * 32 + 16 * s2 >= L) continue; }
                         const bf16x8 pf = pack8(sx[kb], 8 * s2);
 #pragma unroll
                         for (int db = 0; db < 2; ++db) {
-                            const bf16x8 vf = load_vt_frag<VTR>(v_lds, kb * 32 + 16 * s2, db, lane, VROWB);
+                            const bf16x8 vf = load_vt_frag<VTR, RES>(v_t, kb * 32 + 16 * s2, db, lane, VROWB);
                             ox[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ox[db], 0, 0, 0);
                         }
                     }
@@ -591,14 +674,14 @@ static bool use_vtr() {
     return !(e && e[0] == '0');
 }
 
-template <int NW, int QPW, bool XQ = false>
+template <int NW, int QPW, bool XQ = false, bool RES = false>
 static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
     const int rows = NW * QPW * 32;
     dim3 grid(XQ ? 1 : (a.L + rows - 1) / rows, a.heads, a.nseq);
-    if (use_vtr())
-        hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ>), grid, dim3(NW * 64), 0, s, a);
-    else
-        hipLaunchKernelGGL((attn_kernel<false, NW, QPW, XQ>), grid, dim3(NW * 64), 0, s, a);
+    if (RES || use_vtr())
+        hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ, RES>), grid, dim3(NW * 64), 0, s, a);
+    else if constexpr (!RES)
+        hipLaunchKernelGGL((attn_kernel<false, NW, QPW, XQ, false>), grid, dim3(NW * 64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -616,7 +699,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     if (force && force[0] == '4') return launch_attn_cfg<4, 2>(a, s);
     if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
     // 8 full tiles + 1..8 rows (257 / 261 tokens): 4 x 2 block, the extra rows split over the waves by key tile
-    if (a.L > 256 && a.L <= 256 + XQ_ROWS && !a.mx_q) return launch_attn_cfg<4, 2, true>(a, s);
+    if (a.L > 256 && a.L <= 256 + XQ_ROWS && !a.mx_q) {
+        if (force && force[0] == 'x') return launch_attn_cfg<4, 2, true>(a, s);  // streamed K / V tiles (A/B of the resident form)
+        if (use_vtr()) return launch_attn_cfg<4, 2, true, true>(a, s);           // all K / V rows resident in LDS
+        return launch_attn_cfg<4, 2, true>(a, s);
+    }
     if (a.L >= 1024) return launch_attn_cfg<4, 2>(a, s);
     const int pad9 = (t32 + 8) / 9 * 9 - t32, pad8 = (t32 + 7) / 8 * 8 - t32;
     if (pad9 < pad8) return launch_attn_cfg<3, 3>(a, s);

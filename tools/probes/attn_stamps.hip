@@ -46,27 +46,29 @@ int main(int argc, char** argv) {
     printf("nseq %d L %d heads %d t32 %d: %.1f us per launch (stamped build)\n", nseq, L, heads, t32, ms * 100);
     std::vector<unsigned long long> hs(nblk * nw * 32);
     hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-    // per wave: stamp differences; s_memtime ticks at 100 MHz? (MI355X: shader clock) -- report raw ticks and shares
-    const int ntiles = (L + 63) / 64;
-    std::vector<double> seg(40, 0.0);
-    long nwaves = 0; double life = 0;
+    // per wave: mean offset of every stamp from stamp 0 (stamps a kernel form does not execute stay 0 and are skipped)
+    std::vector<double> at(32, 0.0);
+    std::vector<long> cnt(32, 0);
+    long nwaves = 0;
     for (size_t w = 0; w < nblk * nw; ++w) {
         const unsigned long long* s = &hs[w * 32];
         if (!s[0] || !s[31]) continue;
-        ++nwaves; life += (double)(s[31] - s[0]);
-        seg[0] += (double)(s[1] - s[0]);                    // Q loads + first tile loads ISSUED
-        for (int t = 0; t < ntiles; ++t) {
-            const unsigned long long prev = t == 0 ? s[1] : s[5 + 4 * (t - 1)];
-            seg[1] += (double)(s[2 + 4 * t] - prev);        // barrier 1 (previous compute of other waves)
-            seg[2] += (double)(s[3 + 4 * t] - s[2 + 4 * t]);  // wait for the tile's global loads + LDS write
-            seg[3] += (double)(s[4 + 4 * t] - s[3 + 4 * t]);  // barrier 2
-            seg[4] += (double)(s[5 + 4 * t] - s[4 + 4 * t]);  // next-tile load issue + compute
-        }
-        seg[5] += (double)(s[30] - s[5 + 4 * (ntiles - 1)]);
-        seg[6] += (double)(s[31] - s[30]);                  // epilogue
+        ++nwaves;
+        for (int k = 1; k < 32; ++k)
+            if (s[k]) { at[k] += (double)(s[k] - s[0]); ++cnt[k]; }
     }
-    const char* names[] = {"prologue issue", "barrier A (wait other waves)", "wait loads + LDS write", "barrier B", "compute (+ next load issue)", "-", "epilogue"};
-    printf("waves %ld, mean lifetime %.0f ticks\n", nwaves, life / nwaves);
-    for (int i = 0; i < 7; ++i) printf("  %-32s %8.0f ticks  %5.1f %%\n", names[i], seg[i] / nwaves, 100.0 * seg[i] / life);
+    printf("waves %ld; stamp: mean cycles since kernel entry (delta to the previous executed stamp)\n", nwaves);
+    const char* what[32] = {};
+    what[1] = "loads issued (streamed) / all K,V landed + barrier (resident)";
+    what[30] = "key-tile loop done"; what[31] = "outputs stored";
+    double prev = 0;
+    for (int k = 1; k < 32; ++k) {
+        if (!cnt[k]) continue;
+        const double v = at[k] / cnt[k];
+        char buf[64] = "";
+        if (k >= 2 && k < 30) snprintf(buf, sizeof buf, "tile %d: %s", (k - 2) / 4, ((k - 2) % 4 == 0) ? "barrier A passed" : ((k - 2) % 4 == 1) ? "tile written to LDS" : ((k - 2) % 4 == 2) ? "barrier B passed" : "computed");
+        printf("  stamp %2d  %9.0f  (+%7.0f)  %s\n", k, v, v - prev, what[k] ? what[k] : buf);
+        prev = v;
+    }
     return 0;
 }
