@@ -289,23 +289,35 @@ def main():
 
     multi_gpu = None
     if multi and not args.no_multi:
+        # Extra legs: they must never cost the headline line. Every rank runs the same code on the same plan, so an exception is
+        # raised on all ranks alike (no rank is left waiting in a collective); it is reported instead of propagated.
         multi_gpu = {"ranks": world, "videos_per_rank": B}
-        multi_gpu["dp_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / (elapsed if not headline_units else timed(step_dp)), 1)
-        for ex in ("all_to_all", "all_gather"):
-            if headline_units and ex == args.exchange:
-                el, dp_ = elapsed, dpath
-            else:
-                st, dp_ = make_units_step(ex)
-                el = timed(st)
-            multi_gpu[f"units_{ex}_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / el, 1)
-            multi_gpu[f"units_{ex}_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
-        # latency placement: ONE video spread over all ranks (LanguageBind by clip, DINOv2 / SigLIP by frame
-        # ranges, ViViT whole), projected rows all-gathered, every rank fuses (so each holds the tokens for its prefill)
-        st, dp_ = make_units_step("all_gather", n_videos=1, replicate=True)
-        el = timed(st)
-        multi_gpu["one_video_latency_ms"] = round(el / args.steps * 1e3, 3)
-        multi_gpu["one_video_plan"] = dp_.describe_plan()
-        multi_gpu["one_video_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
+        try:
+            multi_gpu["dp_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / (elapsed if not headline_units else timed(step_dp)), 1)
+            for ex in ("all_to_all", "all_gather"):
+                if headline_units and ex == args.exchange:
+                    el, dp_ = elapsed, dpath
+                else:
+                    st, dp_ = make_units_step(ex)
+                    el = timed(st)
+                multi_gpu[f"units_{ex}_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / el, 1)
+                multi_gpu[f"units_{ex}_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
+            # latency placement: ONE video spread over all ranks (LanguageBind by clip, DINOv2 / SigLIP by frame
+            # ranges, ViViT whole), projected rows all-gathered, every rank fuses (so each holds the tokens for its prefill)
+            st, dp_ = make_units_step("all_gather", n_videos=1, replicate=True)
+            el = timed(st)
+            multi_gpu["one_video_latency_ms"] = round(el / args.steps * 1e3, 3)
+            multi_gpu["one_video_plan"] = dp_.describe_plan()
+            multi_gpu["one_video_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
+            if world == 4:  # the literal configs[2] placement for comparison: encoder e on rank e
+                from merv_amd.distributed import DistributedVisualPath
+                dpe = DistributedVisualPath(path, specs, world, rank, None, exchange="all_gather", n_videos=1, replicate_fusion=True,
+                                            placement="per_encoder")
+                upe = dpe.synth_unit_pixels(seed=1234)
+                multi_gpu["one_video_one_encoder_per_gpu_latency_ms"] = round(timed(lambda: dpe.forward(upe)) / args.steps * 1e3, 3)
+        except Exception as e:  # noqa: BLE001
+            multi_gpu["error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: multi-GPU extra legs failed: {multi_gpu['error']}", file=sys.stderr, flush=True)
 
     # ---- roofline leg: the same K steps again with every GEMM launch bracketed by HIP events on its own stream.
     # Kernel durations are only well defined when kernels do not overlap, so this pass runs the encoders on ONE
