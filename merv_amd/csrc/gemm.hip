@@ -508,11 +508,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     const int a_rd = (wr * WTM + frow) * ROW_BYTES, b_rd = A_BYTES + (wc * WTN + frow) * ROW_BYTES;
     const int coff0 = ((0 + fq) ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
 
-    // prologue: all of tile 0 and the early quarters of tile 1 (the launcher guarantees nkt >= 4)
+    // prologue: all of tile 0 and the early quarters of tile 1 are requested (the launcher guarantees nkt >= 4), but the first
+    // phase only needs tile 0's EARLY quarters (32 of its 64 KB): the wait releases those, and tile 0's late quarters are waited
+    // for inside its own first two phases (FIRST mode of k_tile) -- every CU of a round starts its tile at once, so the prologue
+    // is bandwidth-bound and half the bytes arrive in about half the time
     dma_s(0, 0);
     dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
     dma_a(0, 1, 1); dma_b(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // trailing group: one barrier behind from here on
 
@@ -631,22 +634,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     } while (0)
     // one K-tile; MODE 0: tiles t+1 and t+2 exist, 1: only t+1 (second-last tile), 2: last tile -- compile-time, so every
     // body is straight-line code (the launcher only takes this kernel for an even number of K-tiles >= 4)
-    auto k_tile = [&](int t, auto buf_tag, auto mode_tag) {
+    // FIRST (tile 0 only, MODE 0): tile 0's late quarters were not waited for in the prologue. Its B-late quarter is read in
+    // phase 2 and its A-late quarter in phase 3, so phases 1 and 2 each retire one of them before their first barrier (the
+    // wave's queue then holds, youngest last: [the quarter wanted][the other late quarter or nothing][tile 1: A-early, B-early,
+    // (MX scales), B-late, (A-late)] -> all but the 8 (MX: 9) youngest), one phase ahead of the read as the ordering rule asks.
+    auto k_tile = [&](int t, auto buf_tag, auto mode_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
+        static_assert(!FIRST || MODE == 0, "the first tile always has two successors");
         // phase 1
         read_scales(BUF);
         read_w(BUF, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(BUF, 0);
         if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
+        if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I0{});
         MERV_PH_DONE();
         // phase 2
         read_w(BUF, 1);
         if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
+        if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I1{});
         MERV_PH_DONE();
@@ -667,13 +678,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         quadrant(I1{}, I0{});
         MERV_PH_DONE();
     };
-    int t = 0;
+    k_tile(0, I0{}, I0{}, std::true_type{});
+    k_tile(1, I1{}, I0{}, std::false_type{});
+    int t = 2;
     for (; t + 2 < nkt; t += 2) {
-        k_tile(t, I0{}, I0{});
-        k_tile(t + 1, I1{}, I0{});
+        k_tile(t, I0{}, I0{}, std::false_type{});
+        k_tile(t + 1, I1{}, I0{}, std::false_type{});
     }
-    k_tile(t, I0{}, I1{});
-    k_tile(t + 1, I1{}, std::integral_constant<int, 2>{});
+    k_tile(t, I0{}, I1{}, std::false_type{});
+    k_tile(t + 1, I1{}, std::integral_constant<int, 2>{}, std::false_type{});
 #undef MERV_PH_LOADED
 #undef MERV_PH_DONE
 #undef MERV_MX_MMA
