@@ -165,7 +165,7 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
     t0 = time.perf_counter(); m.encode(vv); torch.cuda.synchronize(); t_enc = time.perf_counter() - t0
     dec = next(iter(llm._decoders.values()))
     res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill on PyTorch-ROCm (SDPA), "
-                   f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 7 launches per layer" if type(dec).__name__ == "HipDecoder"
+                   f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 5 launches per layer" if type(dec).__name__ == "HipDecoder"
                                                                 else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
            "new_tokens": int(out.shape[1]), "total_s": round(t, 4), "generated_tok_per_s": round(out.shape[1] / t, 2),
            "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": TOKENS_PER_VIDEO + len(prompt)}

@@ -287,7 +287,7 @@ int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flo
 /*
  * Batch-1 token decode of the LLM hand-off: the per-token forward HF GenerationMixin runs for
  * the reference's generate() (merv/models/vidlms/merv.py:818-825 -> LlamaForCausalLM.forward with a KV cache). The prefill
- * stays on PyTorch-ROCm (north_star); a decode step is 7 launches per layer of these HBM-bound kernels instead of ~35
+ * stays on PyTorch-ROCm (north_star); a decode step is 5 launches per layer of these HBM-bound kernels instead of ~35
  * PyTorch ones. bf16 tensors, fp32 accumulation, bf16 rounding wherever the module materialises a bf16 tensor.
  *  merv_decode_rmsnorm     LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, y [rows, D], w [D]
  *  merv_decode_gemv        nn.Linear at M = 1: y[N] = bf16(W[N,K] x[K]) (+ res[N]); with W2: y = silu(bf16(W x)) * bf16(W2 x)
@@ -312,6 +312,14 @@ int merv_decode_gemv3(const void *Wa, const void *Wb, const void *Wc, const void
 size_t merv_decode_attention_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention(const void *q, const void *k_cache, const void *v_cache, void *out, float *ws, const int64_t *pos,
                           int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, int32_t nsplit, float scale, void *stream);
+/* merv_decode_rope_cache + merv_decode_attention as ONE launch (bit-identical result): every block rotates its head's query, the
+ * token being decoded is rotated from the raw k / v and used from registers (cache[*pos] is written for later steps, never
+ * read here), and the block that arrives last on its head's counter merges the splits. ws: ..._fused_workspace_floats(H, nsplit)
+ * floats, ZEROED by the caller once (the counters at its end return to zero after every launch). */
+size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
+int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
+                                void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
+                                int32_t max_len, int32_t nsplit, float scale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -824,3 +824,21 @@ extern "C" int merv_decode_attention(const void* q, const void* k_cache, const v
     MERV_HIP(launch_decode_attention(a, (hipStream_t)stream_));
     return 0;
 }
+
+extern "C" size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit) {
+    if (H <= 0 || nsplit <= 0) return 0;
+    return (size_t)H * nsplit * (128 + 2) + (size_t)H * 32;  // partials + one arrival counter per head, each on its own 128-byte line
+}
+
+extern "C" int merv_decode_attention_fused(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t,
+                                           const int64_t* pos, void* k_cache, void* v_cache, void* out, float* ws, int32_t H, int32_t Hkv,
+                                           int32_t hd, int32_t max_len, int32_t nsplit, float scale, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && cos_t && sin_t && pos && k_cache && v_cache && out && ws, "merv_decode_attention_fused: null argument");
+    MERV_CHECK(hd == 128, "merv_decode_attention_fused: head_dim must be 128 (Llama-2 / Mistral 7B and 13B)");
+    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attention_fused: bad geometry");
+    DecodeAttnFusedArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
+                          (bf16_t*)v_cache, (bf16_t*)out, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale};
+    MERV_HIP(launch_decode_attention_fused(a, (hipStream_t)stream_));
+    return 0;
+}

@@ -4,7 +4,8 @@
 // The north_star keeps the LLM *prefill* on PyTorch-ROCm. A decode step, though, is ~1100 tiny PyTorch kernels per token
 // (RMSNorm = 8 launches, rotary embedding = 10, ...): measured on MI355X, 6.1 of the 10.4 ms of a graph-replayed
 // Llama-2-7B step are those launches, 4.7 ms the library's M = 1 GEMMs at 2.4-3.4 TB/s (tools/probes/decode_breakdown.py).
-// These kernels are the step as 7 launches per layer, every one a pure HBM stream:
+// These kernels are the step as 5 launches per layer (7 through the separate rotary / attention / merge entry points), every one
+// a pure HBM stream:
 //
 //   rmsnorm_kernel         y = w * bf16(x * rsqrt(mean(x^2) + eps))                    (LlamaRMSNorm.forward)
 //   gemv_kernel            y = bf16(W x) [+ residual]      W [N, K] bf16 streamed once (nn.Linear, M = 1)
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
 constexpr int GEMV_ROWS = 2;   // rows per wave (x chunk reused across them)
 constexpr int GEMV_WAVES = 4;  // waves per block
 
-template <int NW_MATS>  // 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x)
+template <int NW_MATS, int UN>  // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x)
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
@@ -92,48 +93,53 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
         wrow[0][r] = p.W + (size_t)n * p.K;
         if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
     }
-    // fused RMSNorm: the wave reduces mean(x^2) over the whole input once (8 KB, L2-resident; its latency overlaps the first
-    // weight loads issued below), then normalises each chunk it multiplies
+    // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and the x / norm-weight chunks they meet) are in
+    // flight per lane before the first use. Every trip is a full batch: chunks past the row's end are clamped to a valid
+    // address and meet x = 0 (a remainder loop of single loads costs one memory round trip per iteration: 3 us of the
+    // K = 11008 launch).
+    u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[UN];
+    auto issue = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+#pragma unroll
+            for (int m = 0; m < NW_MATS; ++m)
+#pragma unroll
+                for (int r = 0; r < GEMV_ROWS; ++r) wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + cu * 8));
+            xv[u] = *(const u32x4*)(p.x + cu * 8);
+            nv[u] = p.norm_w ? *(const u32x4*)(p.norm_w + cu * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    // fused RMSNorm: the wave reduces mean(x^2) over the whole input once (8 KB, L2-resident) BEHIND the first trip's weight
+    // loads, then normalises each chunk it multiplies
+    int c = lane;
+    if (c < nchunk) issue(c);
     float rstd = 0.f;
     if (p.norm_w) {
         float ss = 0.f;
-        for (int c = lane; c < nchunk; c += 64) {
+        for (int cc = lane; cc < nchunk; cc += 64) {
             float f[8];
-            unpack8f(*(const u32x4*)(p.x + c * 8), f);
+            unpack8f(*(const u32x4*)(p.x + cc * 8), f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
         }
         rstd = rsqrtf(wave_sum64(ss) / (float)p.K + p.norm_eps);
     }
-    auto norm8 = [&](const u32x4& xraw, const u32x4& wraw, float (&xf)[8]) {
-        unpack8f(xraw, xf);
-        if (p.norm_w) {
-            float wn[8];
-            unpack8f(wraw, wn);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] = round_bf(wn[j] * round_bf(xf[j] * rstd));
-        }
-    };
-    // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and the x / norm-weight chunks they meet) are in
-    // flight per lane before the first use
-    constexpr int UN = 4;  // measured on MI355X (step time with Llama-2-7B geometry): UN x ROWS = 4 x 2: 3.36 ms; 2 x 2 3.36; 8 x 2 3.59; 4 x 4 3.53; 4 x 1 3.44; 8 x 1 3.61
-    int c = lane;
-    for (; c + 64 * (UN - 1) < nchunk; c += 64 * UN) {
-        u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-#pragma unroll
-            for (int m = 0; m < NW_MATS; ++m)
-#pragma unroll
-                for (int r = 0; r < GEMV_ROWS; ++r)
-                    wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + (c + 64 * u) * 8));
-            xv[u] = *(const u32x4*)(p.x + (c + 64 * u) * 8);
-            nv[u] = p.norm_w ? *(const u32x4*)(p.norm_w + (c + 64 * u) * 8) : u32x4{0u, 0u, 0u, 0u};
-        }
+    for (; c < nchunk; c += 64 * UN) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             float xf[8];
-            norm8(xv[u], nv[u], xf);
+            unpack8f(xv[u], xf);
+            if (p.norm_w) {
+                float wn[8];
+                unpack8f(nv[u], wn);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = round_bf(wn[j] * round_bf(xf[j] * rstd));
+            }
+            if (c + 64 * u >= nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = 0.f;
+            }
 #pragma unroll
             for (int m = 0; m < NW_MATS; ++m)
 #pragma unroll
@@ -144,19 +150,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
                     for (int j = 0; j < 8; ++j) acc[m][r] = fmaf(wf[j], xf[j], acc[m][r]);
                 }
         }
-    }
-    for (; c < nchunk; c += 64) {
-        float xf[8];
-        norm8(*(const u32x4*)(p.x + c * 8), p.norm_w ? *(const u32x4*)(p.norm_w + c * 8) : u32x4{0u, 0u, 0u, 0u}, xf);
-#pragma unroll
-        for (int m = 0; m < NW_MATS; ++m)
-#pragma unroll
-            for (int r = 0; r < GEMV_ROWS; ++r) {
-                float wf[8];
-                unpack8f(__builtin_nontemporal_load((const u32x4*)(wrow[m][r] + c * 8)), wf);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[m][r] = fmaf(wf[j], xf[j], acc[m][r]);
-            }
+        if (c + 64 * UN < nchunk) issue(c + 64 * UN);
     }
 #pragma unroll
     for (int m = 0; m < NW_MATS; ++m)
@@ -211,6 +205,65 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(DecodeRopeArgs p) {
 // Each block takes positions [s * chunk, (s + 1) * chunk) of [0, pos]; every 16-lane group keeps a running (m, l, o[8]);
 // groups and waves are merged through LDS; the block writes (m, l, o[hd]) to the workspace.
 constexpr int DA_THREADS = 256;
+constexpr int DA_UN = 4;  // cache positions per 16-lane group per trip: 2 x DA_UN 16-byte loads in flight per lane
+
+struct DaState {  // running (max, sum, out[8 dims of this lane]) of one 16-lane group
+    float m, l, o[8];
+};
+MERV_DEVICE float da_dot16(const float (&qf)[8], const float (&kf)[8]) {  // q . k over the group's 128 dims
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d = fmaf(qf[i], kf[i], d);
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
+    return d;
+}
+// one position, from registers
+MERV_DEVICE void da_one(DaState& st, const float (&qf)[8], const float (&kf)[8], const float (&vf)[8], float sc) {
+    const float d = da_dot16(qf, kf) * sc;
+    const float mn = fmaxf(st.m, d);
+    const float a = __builtin_amdgcn_exp2f(st.m - mn), e = __builtin_amdgcn_exp2f(d - mn);
+    st.l = st.l * a + e;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.o[i] = fmaf(st.o[i], a, e * vf[i]);
+    st.m = mn;
+}
+// cache positions j0 + g, j0 + g + 16, ... < jc, DA_UN per trip: all K / V rows of a trip are requested before the first is
+// used, and the trip's scores share one running-max update (a trip per position left the kernel waiting for one HBM round
+// trip per position: 15 us per layer at 1050 positions for 17 MB of cache)
+MERV_DEVICE void da_range(DaState& st, const float (&qf)[8], const bf16_t* Kc, const bf16_t* Vc, int j0, int jc, int g, int sub, float sc) {
+    for (int j = j0 + g; j < jc; j += 16 * DA_UN) {
+        u32x4 kr[DA_UN], vr[DA_UN];
+#pragma unroll
+        for (int u = 0; u < DA_UN; ++u) {
+            const int ju = j + 16 * u < jc ? j + 16 * u : j;  // past the range: a valid row, its score is masked below
+            kr[u] = *(const u32x4*)(Kc + (size_t)ju * 128 + sub * 8);
+            vr[u] = *(const u32x4*)(Vc + (size_t)ju * 128 + sub * 8);
+        }
+        float d[DA_UN], mn = st.m;
+#pragma unroll
+        for (int u = 0; u < DA_UN; ++u) {
+            float kf[8];
+            unpack8f(kr[u], kf);
+            d[u] = j + 16 * u < jc ? da_dot16(qf, kf) * sc : -INFINITY;
+            mn = fmaxf(mn, d[u]);
+        }
+        const float a = __builtin_amdgcn_exp2f(st.m - mn);  // position j itself is in range: mn is finite
+        st.l *= a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.o[i] *= a;
+#pragma unroll
+        for (int u = 0; u < DA_UN; ++u) {
+            const float e = __builtin_amdgcn_exp2f(d[u] - mn);
+            float vf[8];
+            unpack8f(vr[u], vf);
+            st.l += e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) st.o[i] = fmaf(e, vf[i], st.o[i]);
+        }
+        st.m = mn;
+    }
+}
+
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(DecodeAttnArgs p) {
     __shared__ float sm_m[16], sm_l[16];
     __shared__ __attribute__((aligned(16))) float sm_o[16][128];
@@ -226,29 +279,23 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_kernel(DecodeAttnArgs 
     unpack8f(*(const u32x4*)(p.q + h * 128 + sub * 8), qf);
     const bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
     const bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
-    float m = -INFINITY, l = 0.f, o[8];
+    DaState st;
+    st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = 0.f;
+    for (int i = 0; i < 8; ++i) st.o[i] = 0.f;
     const float sc = p.scale * 1.4426950408889634f;
-    for (int j = j0 + g; j < j1; j += 16) {
+    const long pos = npos - 1;
+    // the token being decoded is taken last, by the group whose turn it is (the order the fused launch uses: same bits)
+    da_range(st, qf, Kc, Vc, j0, j1 < pos ? j1 : (int)pos, g, sub, sc);
+    if (pos >= j0 && pos < j1 && g == (int)((pos - j0) & 15)) {
         float kf[8], vf[8];
-        unpack8f(*(const u32x4*)(Kc + (size_t)j * 128 + sub * 8), kf);
-        unpack8f(*(const u32x4*)(Vc + (size_t)j * 128 + sub * 8), vf);
-        float d = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d = fmaf(qf[i], kf[i], d);
-        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 8, 64);
-        d *= sc;
-        const float mn = fmaxf(m, d);
-        const float a = __builtin_amdgcn_exp2f(m - mn), e = __builtin_amdgcn_exp2f(d - mn);
-        l = l * a + e;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = fmaf(o[i], a, e * vf[i]);
-        m = mn;
+        unpack8f(*(const u32x4*)(Kc + (size_t)pos * 128 + sub * 8), kf);
+        unpack8f(*(const u32x4*)(Vc + (size_t)pos * 128 + sub * 8), vf);
+        da_one(st, qf, kf, vf, sc);
     }
-    if (sub == 0) { sm_m[g] = m; sm_l[g] = l; }
+    if (sub == 0) { sm_m[g] = st.m; sm_l[g] = st.l; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm_o[g][sub * 8 + i] = o[i];
+    for (int i = 0; i < 8; ++i) sm_o[g][sub * 8 + i] = st.o[i];
     __syncthreads();
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
@@ -283,6 +330,122 @@ __global__ __launch_bounds__(128) void decode_attn_merge_kernel(DecodeAttnArgs p
     p.out[h * 128 + d] = f2bf(O / L);
 }
 
+// ---- rotary + cache update + split attention + merge in one launch: grid (H, nsplit), 256 threads ----
+// What the three launches above do, without the two kernel boundaries between them (each ~5 us of drain + ramp in a step that
+// is one dependent chain): every block rotates its head's query itself (128 values); positions 0 .. pos-1 come from the cache;
+// the token being decoded is rotated from the raw k / v by the one 16-lane group whose turn it is and used from registers --
+// no block reads cache[pos] -- and the first head of each kv group stores it for the steps to come. The partials meet through
+// the workspace: a block publishes (o, m, l), fences, and takes a ticket on its head's counter; the block that draws the last
+// ticket merges all splits and resets the counter (so a captured graph replays). Same rounding points as the separate kernels.
+// Measured (tools/probes/decode_kernels.py, 1050 positions): 13.7 us per layer with 8 splits of 256 threads; 17.9 / 24.0 with
+// 16 / 32 splits, 16.5 with one 1024-thread block per head and no workspace round trip, 12.5-13.8 with 1024-thread blocks
+// and 2-8 splits -- the launch is a chain of dependent memory round trips (position -> tables / q / cache rows -> partials ->
+// ticket -> partials), not a bandwidth problem (17 MB of cache).
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAttnFusedArgs p) {
+    __shared__ float sm_m[16], sm_l[16];
+    __shared__ __attribute__((aligned(16))) float sm_o[16][128];
+    __shared__ unsigned sm_ticket;
+    const int h = blockIdx.x, s = blockIdx.y;
+    const int grp_heads = p.H / p.Hkv;
+    const int hkv = h / grp_heads;
+    const long pos = *p.pos;
+    const long npos = pos + 1;
+    const int chunk = (int)((npos + p.nsplit - 1) / p.nsplit);
+    const int j0 = s * chunk, j1 = (long)(j0 + chunk) < npos ? j0 + chunk : (int)npos;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int g = wave * 4 + grp;
+    // rotary at *pos: lane `sub` owns dims 8 sub .. 8 sub + 7, their rotate_half partners sit in lane sub ^ 8 of the group
+    float cf[8], sf[8];
+    unpack8f(*(const u32x4*)(p.cos + pos * 128 + sub * 8), cf);
+    unpack8f(*(const u32x4*)(p.sin + pos * 128 + sub * 8), sf);
+    auto rotary = [&](const bf16_t* vec, float (&r)[8]) {
+        const u32x4 own = *(const u32x4*)(vec + sub * 8);
+        u32x4 oth;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) oth[q] = __shfl_xor(own[q], 8, 64);
+        float a[8], b[8];
+        unpack8f(own, a);
+        unpack8f(oth, b);
+        const float sgn = sub < 8 ? -1.f : 1.f;  // rotate_half: (-x[d + half], x[d - half])
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = round_bf(round_bf(a[i] * cf[i]) + round_bf(sgn * b[i] * sf[i]));
+    };
+    float qf[8];
+    rotary(p.q + h * 128, qf);
+    bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
+    bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
+    DaState st;
+    st.m = -INFINITY; st.l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.o[i] = 0.f;
+    const float sc = p.scale * 1.4426950408889634f;
+    da_range(st, qf, Kc, Vc, j0, j1 < pos ? j1 : (int)pos, g, sub, sc);  // cached positions of this range end before the current token
+    if (pos >= j0 && pos < j1 && g == (int)((pos - j0) & 15)) {  // uniform per 16-lane group: the shuffles inside stay in the group
+        float kf[8], vf[8];
+        rotary(p.k + hkv * 128, kf);
+        const u32x4 vraw = *(const u32x4*)(p.v + hkv * 128 + sub * 8);
+        unpack8f(vraw, vf);
+        da_one(st, qf, kf, vf, sc);
+        if (h % grp_heads == 0) {
+            u32x4 kr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kr[q] = pack2bf(kf[2 * q], kf[2 * q + 1]);
+            *(u32x4*)(Kc + (size_t)pos * 128 + sub * 8) = kr;
+            *(u32x4*)(Vc + (size_t)pos * 128 + sub * 8) = vraw;
+        }
+    }
+    if (sub == 0) { sm_m[g] = st.m; sm_l[g] = st.l; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm_o[g][sub * 8 + i] = st.o[i];
+    __syncthreads();
+    float* ws_h = p.ws + (size_t)h * p.nsplit * (128 + 2);
+    if (threadIdx.x < 128) {
+        const int d = threadIdx.x;
+        float M = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) M = fmaxf(M, sm_m[q]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float w = sm_m[q] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_m[q] - M);
+            L = fmaf(w, sm_l[q], L);
+            O = fmaf(w, sm_o[q][d], O);
+        }
+        // the partials travel between blocks (possibly between XCDs, each with its own L2) inside one launch: device-scope
+        // relaxed atomics write through / read past the non-coherent cache levels, which costs nothing beside an ordinary
+        // store here, whereas a device-scope FENCE writes back and invalidates the whole L2 (measured: +15 us per layer)
+        float* ws = ws_h + (size_t)s * (128 + 2);
+        __hip_atomic_store(ws + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == 0) {
+            __hip_atomic_store(ws + 128, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws + 129, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // publish (every store of this block acknowledged), then take a ticket; the last arrival of this head merges
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    unsigned* counter = (unsigned*)(p.ws + (size_t)p.H * p.nsplit * (128 + 2)) + h * 32;  // one 128-byte line per head
+    if (threadIdx.x == 0) sm_ticket = atomicAdd(counter, 1u);
+    __syncthreads();
+    if (sm_ticket != (unsigned)(p.nsplit - 1)) return;
+    if (threadIdx.x < 128) {
+        const int d = threadIdx.x;
+        auto ld = [&](int i) { return __hip_atomic_load(ws_h + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        float M = -INFINITY;
+        for (int q = 0; q < p.nsplit; ++q) M = fmaxf(M, ld(q * 130 + 128));
+        float L = 0.f, O = 0.f;
+        for (int q = 0; q < p.nsplit; ++q) {
+            const float ms = ld(q * 130 + 128);
+            const float w = ms == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+            L = fmaf(w, ld(q * 130 + 129), L);
+            O = fmaf(w, ld(q * 130 + d), O);
+        }
+        p.out[h * 128 + d] = f2bf(O / L);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
@@ -301,8 +464,9 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
             return hipErrorInvalidValue;
     }
     dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
-    if (a.W2) hipLaunchKernelGGL(gemv_kernel<2>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
-    else hipLaunchKernelGGL(gemv_kernel<1>, grid, dim3(GEMV_WAVES * 64), 0, s, a);
+    // UN (chunks per lane per trip), step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms, 8: 4.60 ms
+    if (a.W2) hipLaunchKernelGGL((gemv_kernel<2, 4>), grid, dim3(GEMV_WAVES * 64), 0, s, a);
+    else hipLaunchKernelGGL((gemv_kernel<1, 4>), grid, dim3(GEMV_WAVES * 64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -318,6 +482,12 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(decode_attn_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     hipLaunchKernelGGL(decode_attn_merge_kernel, dim3(a.H), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s) {
+    if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -306,4 +306,20 @@ struct DecodeAttnArgs {  // softmax(q K^T * scale) V over cache positions 0 .. *
 };
 hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s);
 
+struct DecodeAttnFusedArgs {  // rotary(q, k at *pos) + cache[*pos] <- k, v + split attention + merge, ONE launch; hd == 128
+    const bf16_t* q;     // [H * hd] raw q_proj output
+    const bf16_t* k;     // [Hkv * hd] raw k_proj output
+    const bf16_t* v;     // [Hkv * hd]
+    const bf16_t* cos;   // [max_len, hd]
+    const bf16_t* sin;
+    bf16_t* k_cache;     // [Hkv, max_len, hd]
+    bf16_t* v_cache;
+    bf16_t* out;         // [H * hd]
+    float* ws;           // [H][nsplit][hd + 2] partial (o, m, l), then H arrival counters (uint32, zero between launches)
+    const long* pos;
+    int H, Hkv, hd, max_len, nsplit;
+    float scale;
+};
+hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s);
+
 }  // namespace merv

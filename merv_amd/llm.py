@@ -274,8 +274,8 @@ class StaticDecoder:
 
 
 class HipDecoder(StaticDecoder):
-    """The batch-1 decode step of `StaticDecoder` on libmerv_hip.so's decode kernels (csrc/decode.hip): 7 launches per layer
-    -- the q / k / v projections as one GEMV launch with the input RMSNorm fused in, rotary + cache update, split attention + merge, o-projection with the residual, the
+    """The batch-1 decode step of `StaticDecoder` on libmerv_hip.so's decode kernels (csrc/decode.hip): 5 launches per layer
+    -- the q / k / v projections as one GEMV launch with the input RMSNorm fused in, rotary + cache update + split attention + merge as one launch, o-projection with the residual, the
     gated MLP as one GEMV pair with its RMSNorm and silu * up fused, down-projection with the residual -- instead of ~35 PyTorch ones, each a
     pure HBM stream (weights read once, non-temporal). Same parameters (the HF module's, no copies), same static cache and
     rotary tables, same rounding points as the bf16 module; prefill stays on PyTorch-ROCm (north_star). Measured on MI355X
@@ -300,8 +300,9 @@ class HipDecoder(StaticDecoder):
         D, I = cfg.hidden_size, cfg.intermediate_size
         mk = lambda n, dt=self.dt: torch.empty(n, dtype=dt, device=self.dev)
         self.x, self.h, self.ao, self.mid = mk(D), mk(D), mk(self.H * self.hd), mk(I)
-        self.q, self.q2, self.k, self.v = mk(self.H * self.hd), mk(self.H * self.hd), mk(self.Hkv * self.hd), mk(self.Hkv * self.hd)
-        self.ws = mk(self.lib.merv_decode_attention_workspace_floats(self.H, self.NSPLIT), torch.float32)
+        self.q, self.k, self.v = mk(self.H * self.hd), mk(self.Hkv * self.hd), mk(self.Hkv * self.hd)
+        # partials of the split attention + one arrival counter per head (zero between launches: the kernel restores them)
+        self.ws = torch.zeros(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT), dtype=torch.float32, device=self.dev)
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
 
     def _step(self):
@@ -323,10 +324,9 @@ class HipDecoder(StaticDecoder):
                 check(lib.merv_decode_gemv3(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), x, ptr(self.q), ptr(self.k),
                                             ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps, st),
                       "merv_decode_gemv3")
-                check(lib.merv_decode_rope_cache(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]),
-                                                 ptr(self.cos), ptr(self.sin), pos, H, Hkv, hd, self.max_len, st), "merv_decode_rope_cache")
-                check(lib.merv_decode_attention(ptr(self.q2), ptr(self.K[li]), ptr(self.V[li]), ptr(self.ao), ptr(self.ws), pos, H, Hkv,
-                                                hd, self.max_len, self.NSPLIT, hd**-0.5, st), "merv_decode_attention")
+                check(lib.merv_decode_attention_fused(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
+                                                      ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT,
+                                                      hd**-0.5, st), "merv_decode_attention_fused")
                 gemv(a.o_proj.weight, None, ptr(self.ao), x, x, D, H * hd)  # x += o_proj(attn)
                 gemv(mlp.gate_proj.weight, mlp.up_proj.weight, x, 0, ptr(self.mid), I, D, norm=lyr.post_attention_layernorm.weight)
                 gemv(mlp.down_proj.weight, None, ptr(self.mid), x, x, D, I)  # x += down_proj(...)

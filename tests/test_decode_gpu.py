@@ -126,6 +126,58 @@ def test_rope_cache_and_attention(dev, H, Hkv, pos):
     assert rel_l2(out, ref) < 6e-3
 
 
+@pytest.mark.parametrize("H,Hkv,pos", [(32, 32, 0), (32, 8, 5), (4, 1, 1048), (8, 8, 300), (2, 2, 7), (32, 32, 1111), (32, 8, 15), (32, 8, 16)])
+def test_fused_attention_launch_equals_the_three_kernels(dev, H, Hkv, pos):
+    """merv_decode_attention_fused (rotary + cache write + split attention + last-arrival merge in one launch) gives the bits
+    of merv_decode_rope_cache -> merv_decode_attention, leaves the same cache behind, and its arrival counters return to zero
+    (three back-to-back launches on the same workspace, as a replayed graph would issue them)."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    hd, max_len, ns = 128, 1280, 8
+    g = torch.Generator().manual_seed(H * 1000 + pos + 1)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    q, k, v = bf(torch.randn(H * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g))
+    Kc, Vc = bf(torch.randn(Hkv, max_len, hd, generator=g)), bf(torch.randn(Hkv, max_len, hd, generator=g))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    emb = torch.outer(torch.arange(max_len, dtype=torch.float32), inv)
+    emb = torch.cat([emb, emb], -1)
+    cos, sin = bf(emb.cos()), bf(emb.sin())
+    p = torch.tensor([pos], dtype=torch.int64, device=dev)
+    Ka, Va, q2 = Kc.clone(), Vc.clone(), torch.empty_like(q)
+    out_a = torch.empty(H * hd, dtype=torch.bfloat16, device=dev)
+    ws_a = torch.empty(lib.merv_decode_attention_workspace_floats(H, ns), dtype=torch.float32, device=dev)
+    check(lib.merv_decode_rope_cache(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(Ka), ptr(Va), ptr(cos), ptr(sin), ptr(p), H, Hkv, hd, max_len,
+                                     _st(dev)), "rope")
+    check(lib.merv_decode_attention(ptr(q2), ptr(Ka), ptr(Va), ptr(out_a), ptr(ws_a), ptr(p), H, Hkv, hd, max_len, ns, hd**-0.5, _st(dev)), "attn")
+    n_ws = lib.merv_decode_attention_fused_workspace_floats(H, ns)
+    assert n_ws == H * ns * 130 + 32 * H
+    ws = torch.zeros(n_ws, dtype=torch.float32, device=dev)
+    for rep in range(3):
+        Kb, Vb = Kc.clone(), Vc.clone()
+        out_b = torch.full((H * hd,), float("nan"), dtype=torch.bfloat16, device=dev)
+        check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(out_b), ptr(ws),
+                                              H, Hkv, hd, max_len, ns, hd**-0.5, _st(dev)), "fused")
+        torch.cuda.synchronize()
+        assert torch.equal(out_b, out_a), rep
+        assert torch.equal(Kb, Ka) and torch.equal(Vb, Va)
+        assert int(ws[H * ns * 130:].view(torch.int32).abs().sum()) == 0  # counters back at zero
+    # one split (the ticket drawn is at once the last): another summation order, so against the fp32 restatement
+    Kb, Vb = Kc.clone(), Vc.clone()
+    out_c = torch.full((H * hd,), float("nan"), dtype=torch.bfloat16, device=dev)
+    ws = torch.zeros(lib.merv_decode_attention_fused_workspace_floats(H, 1), dtype=torch.float32, device=dev)  # the counters sit behind H * nsplit partials
+    check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(out_c), ptr(ws),
+                                          H, Hkv, hd, max_len, 1, hd**-0.5, _st(dev)), "fused1")
+    torch.cuda.synchronize()
+    assert torch.equal(Kb, Ka) and torch.equal(Vb, Va)
+    rep = H // Hkv
+    Kf = Ka[:, : pos + 1].float().repeat_interleave(rep, 0)
+    Vf = Va[:, : pos + 1].float().repeat_interleave(rep, 0)
+    att = torch.softmax((q2.view(H, 1, hd).float() @ Kf.transpose(1, 2)) * hd**-0.5, -1)
+    ref = (att @ Vf).reshape(-1)
+    assert rel_l2(out_c, ref) < 6e-3 and rel_l2(out_c, out_a) < 6e-3
+
+
 @pytest.mark.parametrize("kv_heads,family", [(2, "llama"), (1, "mistral")])
 def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
     """Same random model, same prefill (PyTorch-ROCm, as the north_star keeps it), then token-by-token decode on both decoders,
