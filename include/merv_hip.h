@@ -130,6 +130,20 @@ int merv_encoder_forward_frames(const merv_encoder *enc, const void *pixels, int
                                 int32_t frames, void *out_tokens, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * The same forward with the token selection spelled out. MERV_OUT_PATCHES: what merv_encoder_forward returns (prefix tokens
+ * stripped). MERV_OUT_ALL: every token of every sequence, prefix tokens first -- [B, frames/tubelet, prefix + S, D] for
+ * per-frame encoders, [B, prefix + T*S, D] for a joint space-time encoder -- for the registry's other token selections
+ * (merv/models/materialize.py:31-73: `classemb`, `average`, `classemb-at-first`, `all-token-with-cls`, `cls-token`, ...:
+ * languagebind/__init__.py:88-98, dinov2_video.py:140-151, vivit.py:106-118), which are views / means of this tensor.
+ */
+#define MERV_OUT_PATCHES 0
+#define MERV_OUT_ALL 1
+int merv_encoder_forward_select(const merv_encoder *enc, const void *pixels, int32_t pix_dtype, int32_t batch, int32_t frames,
+                                int32_t select, void *out_tokens, void *workspace, size_t workspace_bytes, void *stream);
+/* out[g] = bf16(mean over r < rows of x[g * group_stride_rows + r]) (fp32 accumulation: torch.mean of a bf16 tensor), rows of D */
+int merv_mean_rows(const void *x, void *out, int32_t groups, int32_t rows, int32_t D, int64_t group_stride_rows, void *stream);
+
+/*
  * AveragePooling3DProjector.forward with mlp_type="linear" (merv/util/nn_utils.py:320-330, :31-32):
  * tokens [B, T*S*S, C] -> AdaptiveAvgPool3d((T, out_size, out_size)) -> Linear(C -> llm_dim) -> [B, T*out^2, llm_dim].
  * pooled_ws: scratch of B*T*out^2*C bf16.

@@ -5,9 +5,11 @@ Video backbones with the reference's class names, constructor arguments, propert
 Differences from the reference, all forced by this environment (no network, no timm):
   * weights are not downloaded in __init__; pass `weights=` (an upstream state dict of the matching family or a
     canonical dict, see merv_amd/weights.py) or `weights="random"` for seeded synthetic parameters;
-  * only the token selections used by merv-full / merv-frozen and the single-encoder configs are wired
-    (`*-noclass`, `*-all-tokens`, `*-all-no-cls-16frames`, `*-all-no-cls`); the other registry keys exist and raise
-    NotImplementedError when constructed;
+  * every token selection of the LanguageBind / DINOv2 / ViViT registry keys is wired (a slice, a concatenation or a mean --
+    merv_mean_rows -- of the encoder's full token tensor, merv_encoder_forward_select); of the SigLIP keys only
+    `siglip-vit-b16-224px-all-no-cls`: the others return timm's attention-pooled (MAP head) feature per frame
+    (siglip.py:46-63 leaves the timm forward in place unless the id says all-no-cls) or, for `classemb-at-first`, fail inside
+    the reference itself (a tuple is reshaped, siglip.py:148-149) -- they raise NotImplementedError when constructed;
   * `video_transform` is the GPU implementation of the reference's CPU PIL / torchvision pipelines
     (merv_amd/preprocess.py: Pillow-bit-exact resize + ToTensor + Normalize; LanguageBind's torch pipeline with the
     random flip made an explicit, default-off switch): it takes load_video()'s uint8 [F,3,H,W] tensor on the device.
@@ -60,6 +62,17 @@ class VideoBackbone(nn.Module):
 
     def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.featurizer.forward(video_values)
+
+    def _mean_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """[..., R, D] bf16 -> [..., D]: torch.mean(dim=-2) of a bf16 tensor (fp32 accumulation, one rounding), as a HIP kernel."""
+        from ._lib import check, ptr
+        x = x.contiguous()
+        R, D = x.shape[-2], x.shape[-1]
+        out = torch.empty(*x.shape[:-2], D, dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            check(self.featurizer._lib.merv_mean_rows(ptr(x), ptr(out), x.numel() // (R * D), R, D, R,
+                                                      torch.cuda.current_stream(x.device).cuda_stream), "merv_mean_rows")
+        return out
 
     @property
     def embed_dim(self) -> int:
@@ -142,12 +155,35 @@ class LangBindVideoBackbone(VideoBackbone):
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
         assert "languagebind-video" in video_backbone_id, video_backbone_id
         assert image_resize_strategy == "resize-naive"  # languagebind/__init__.py:64
-        if token != "noclass":
-            raise NotImplementedError(f"LanguageBind token selection `{token}` is not wired on the HIP path (only 'noclass')")
+        if token not in (None, "average", "classemb", "noclass", "classemb-at-first"):
+            raise ValueError(f"LanguageBind token selection `{token}` does not exist (languagebind/__init__.py:88-98)")
         self.token = token
         spec = EncoderSpec("languagebind", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BCFHW", 1, False,
                            True, False, False, 8, hidden_act, 1e-5)
         self._build(spec, weights, device, lambda sd: W.from_languagebind_vision(sd, n_layers=layers), ln_fold)
+
+    def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """languagebind/__init__.py:79-103: hidden_states[-2] [B, F, 257, D], then the `token` rule."""
+        if self.token == "noclass":
+            return self.featurizer.forward(video_values)
+        B, D = video_values.shape[0], self.spec.dim
+        v = self.featurizer.forward(video_values, select="all").view(B, -1, 257, D)
+        if self.token == "average":
+            return self._mean_rows(v)
+        if self.token == "classemb":
+            return v[:, :, 0, :].contiguous()
+        if self.token == "classemb-at-first":
+            cls = self._mean_rows(v[:, :, 0, :]).unsqueeze(1)  # mean over the frames of the per-frame class tokens
+            return torch.cat([cls, v[:, :, 1:, :].reshape(B, -1, D)], 1)
+        return v.reshape(B, -1, D)
+
+    @property
+    def num_patches(self) -> int:  # languagebind/__init__.py:113-126 (classemb-at-first: the class token is not counted)
+        return self.num_frames * {None: 257, "average": 1, "classemb": 1, "noclass": 256, "classemb-at-first": 256}[self.token]
+
+    @property
+    def spatial_resolution(self) -> int:
+        return self.num_patches // self.num_frames
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:
@@ -158,12 +194,15 @@ class DinoV2VideoBackbone(VideoBackbone):
     """dinov2_video.py:27-179 -- timm vit_large_patch14_reg4_dinov2, get_intermediate_layers(n={L-2})."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
-                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 23, ln_fold: bool = True) -> None:
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: Optional[int] = None, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
-        if "all-tokens" not in video_backbone_id:
-            raise NotImplementedError(f"`{video_backbone_id}`: only the all-tokens selection is wired on the HIP path")
+        # dinov2_video.py:46-66: ids with "all-token" / "classemb-at-first" read block L-2 (no final norm); the bare id keeps timm's
+        # forward(): all L blocks, the final norm, the class token of every frame
+        self.pooled = not ("all-token" in video_backbone_id or "classemb-at-first" in video_backbone_id)
+        if layers is None:
+            layers = 24 if self.pooled else 23
         spec = EncoderSpec("dinov2", 1024, 16, 4096, layers, 14, 1, default_image_size, num_frames, "BFCHW", 5, False, False,
-                           False, True, 0, "gelu_erf", 1e-6)
+                           self.pooled, True, 0, "gelu_erf", 1e-6)
         self._build(spec, weights, device,
                     lambda sd: W.from_timm_vit(sd, n_layers=layers, grid=default_image_size // 14), ln_fold)
 
@@ -172,14 +211,38 @@ class DinoV2VideoBackbone(VideoBackbone):
         return (self.num_frames, 3, self.default_image_size, self.default_image_size)
 
 
+    def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dinov2_video.py:132-154."""
+        ident = self.identifier
+        if "all-tokens" in ident:
+            return self.featurizer.forward(video_values)
+        B, D = video_values.shape[0], self.spec.dim
+        v = self.featurizer.forward(video_values, select="all").view(B, -1, 5 + self.spec.s_out, D)  # [B, F, 5 + 256, D]
+        if self.pooled:
+            return v[:, :, 0, :].contiguous()
+        patches = v[:, :, 5:, :].reshape(B, -1, D)
+        cls = v[:, :, 0, :]  # prefix[:, :1]: the class token; the four register tokens are dropped
+        if "classemb-at-first" in ident:
+            cls = self._mean_rows(cls).unsqueeze(1)
+        return torch.cat([cls, patches], 1)
+
+    @property
+    def num_patches(self) -> int:  # dinov2_video.py:164-170, quirks kept ("all-token-with-cls" does not contain "all-tokens")
+        if "classemb-at-first" in self.identifier or "all-tokens" in self.identifier:
+            return self.num_frames * self.spec.s_out
+        return self.num_frames
+
+    @property
+    def spatial_resolution(self) -> int:
+        return self.num_patches // self.num_frames
+
+
 class ViVITVideoBackbone(VideoBackbone):
     """vivit.py:24-155 -- HF VivitModel (google/vivit-b-16x2-kinetics400), last_hidden_state[:, 1:]."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
                  num_frames: int = 32, weights=None, device="cuda:0", layers: int = 12, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
-        if "all-no-cls-16frames" not in video_backbone_id:
-            raise NotImplementedError(f"`{video_backbone_id}`: only all-no-cls-16frames is wired on the HIP path")
         self.video_backbone_id = video_backbone_id
         spec = EncoderSpec("vivit", 768, 12, 3072, layers, 16, 2, default_image_size, num_frames, "BFCHW", 1, True, False, True,
                            False, 0, "gelu_tanh", 1e-6)
@@ -190,14 +253,50 @@ class ViVITVideoBackbone(VideoBackbone):
         return (self.num_frames, 3, self.default_image_size, self.default_image_size)
 
 
+    def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """vivit.py:100-118 on last_hidden_state [B, 3137, D]."""
+        ident = self.video_backbone_id
+        if "all-no-cls-16frames" in ident:
+            return self.featurizer.forward(video_values)
+        v = self.featurizer.forward(video_values, select="all")
+        B, D = v.shape[0], v.shape[-1]
+        if "cls-token" in ident:
+            return v[:, 0].unsqueeze(1).contiguous()
+        if "all-no-cls" in ident:  # every second of the 16 tubelet slots
+            return v[:, 1:].reshape(B, 16, 14, 14, D)[:, ::2].reshape(B, 8 * 14 * 14, D)
+        return v  # all-tokens, classemb-at-first-16frames: neither branch of vivit.py:106-117 fires
+
+    @property
+    def num_patches(self) -> int:  # vivit.py:128-142
+        ident = self.video_backbone_id
+        if "cls-token" in ident:
+            return 1
+        if "all-tokens" in ident:
+            return 3137
+        if "all-no-cls-16frames" in ident or "classemb-at-first" in ident:
+            return 3136
+        if "all-no-cls" in ident:
+            return 3136 // 2
+        raise NotImplementedError(ident)
+
+    @property
+    def spatial_resolution(self) -> int:  # vivit.py:145-151
+        if "all-no-cls" in self.video_backbone_id or "classemb-at-first" in self.video_backbone_id:
+            return 196
+        return self.num_patches
+
+
 class SiglipVideoBackbone(VideoBackbone):
     """siglip.py:35-174 -- timm vit_base_patch16_siglip_224, get_intermediate_layers(n={L-2}), no class token."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
                  num_frames: int = 8, weights=None, device="cuda:0", layers: int = 11, ln_fold: bool = True) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
-        if "siglip-vit-b16-224px-all" not in video_backbone_id:
-            raise NotImplementedError(f"`{video_backbone_id}`: only the B/16-224 all-token selections are wired")
+        if video_backbone_id != "siglip-vit-b16-224px-all-no-cls":
+            raise NotImplementedError(
+                f"`{video_backbone_id}`: only `siglip-vit-b16-224px-all-no-cls` is wired. Ids without `all-no-cls` keep timm's forward() "
+                "(siglip.py:46-63): the attention-pooled MAP-head feature of every frame, which this path does not implement; "
+                "`classemb-at-first` reshapes a tuple in the reference itself (siglip.py:148-149)")
         spec = EncoderSpec("siglip", 768, 12, 3072, layers, 16, 1, default_image_size, num_frames, "BFCHW", 0, False, False,
                            False, False, 0, "gelu_erf", 1e-6)
         self._build(spec, weights, device, lambda sd: W.from_timm_vit(sd, n_layers=layers), ln_fold)

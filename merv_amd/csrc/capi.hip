@@ -304,7 +304,15 @@ extern "C" int merv_encoder_forward(const merv_encoder* e, const void* pixels, i
 extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pixels, int32_t pix_dtype, int32_t batch,
                                            int32_t frames, void* out_tokens, void* workspace, size_t workspace_bytes,
                                            void* stream_) {
+    return merv_encoder_forward_select(e, pixels, pix_dtype, batch, frames, MERV_OUT_PATCHES, out_tokens, workspace, workspace_bytes,
+                                       stream_);
+}
+
+extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pixels, int32_t pix_dtype, int32_t batch,
+                                           int32_t frames, int32_t select, void* out_tokens, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(select == MERV_OUT_PATCHES || select == MERV_OUT_ALL, "merv_encoder_forward_select: bad token selection");
     MERV_CHECK(e && pixels && out_tokens && workspace, "merv_encoder_forward: null argument");
     MERV_CHECK(batch > 0, "merv_encoder_forward: batch must be positive");
     MERV_CHECK(pix_dtype == MERV_DT_F32 || pix_dtype == MERV_DT_BF16, "merv_encoder_forward: bad pixel dtype");
@@ -459,6 +467,9 @@ extern "C" int merv_encoder_forward_frames(const merv_encoder* e, const void* pi
     ga.prefix = d.prefix_tokens;
     if (d.joint_space_time) { ga.bstride = ntok; ga.fstride = e->S_out; }
     else { ga.bstride = seq_per_video * ntok; ga.fstride = ntok; }
+    if (select == MERV_OUT_ALL) {  // every token of every sequence, prefix tokens first: a plain copy of the stream
+        ga.prefix = 0; ga.T = seq_per_video; ga.S = ntok; ga.bstride = seq_per_video * ntok; ga.fstride = ntok;
+    }
     MERV_HIP(launch_gather_tokens(ga, s));
     return 0;
 }
@@ -840,5 +851,15 @@ extern "C" int merv_decode_attention_fused(const void* q, const void* k, const v
     DecodeAttnFusedArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
                           (bf16_t*)v_cache, (bf16_t*)out, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale};
     MERV_HIP(launch_decode_attention_fused(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_mean_rows(const void* x, void* out, int32_t groups, int32_t rows, int32_t D, int64_t group_stride_rows,
+                              void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(x && out, "merv_mean_rows: null argument");
+    MERV_CHECK(groups >= 0 && rows > 0 && D > 0 && D % 8 == 0 && group_stride_rows >= 0, "merv_mean_rows: bad geometry");
+    MeanRowsArgs a{(const bf16_t*)x, (bf16_t*)out, groups, rows, D, group_stride_rows};
+    MERV_HIP(launch_mean_rows(a, (hipStream_t)stream_));
     return 0;
 }

@@ -167,6 +167,16 @@ struct GatherTokensArgs {
 };
 hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s);
 
+// out[g][:] = bf16(mean_r x[g][r][:]), fp32 accumulation (torch's mean on a bf16 tensor). x [groups, rows, D] with a row stride
+// of D and a group stride of group_stride rows.
+struct MeanRowsArgs {
+    const bf16_t* x;
+    bf16_t* out;
+    int groups, rows, D;
+    long long group_stride;  // in rows
+};
+hipError_t launch_mean_rows(const MeanRowsArgs& a, hipStream_t s);
+
 // AdaptiveAvgPool3d((T, Ho, Ho)) over tokens laid out [B, T, S*S, C] (nn_utils.py:320-328); T is kept
 // (output_frames == temporal_resolution for 3davg), spatial S -> Ho with torch's window rule
 // [floor(i*S/Ho), ceil((i+1)*S/Ho)). Output [B*T*Ho*Ho, C] bf16.

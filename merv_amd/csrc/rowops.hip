@@ -215,6 +215,29 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(GatherTokensArgs p) 
     }
 }
 
+// Mean over the rows of each group (token-selection variants of the backbones: per-frame mean over all tokens,
+// mean of the per-frame class tokens). One thread per (group, 8 channels); the row loop reads 16 B per lane, coalesced over c.
+__global__ __launch_bounds__(256) void mean_rows_kernel(MeanRowsArgs p) {
+    const int dc = p.D >> 3;
+    const long long total = (long long)p.groups * dc;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const int c = (int)(g % dc);
+        const long long grp = g / dc;
+        const bf16_t* base = p.x + (size_t)grp * p.group_stride * p.D + c * 8;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < p.rows; ++r) {
+            const u32x4 v = *(const u32x4*)(base + (size_t)r * p.D);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { acc[2 * q] += bflo(v[q]); acc[2 * q + 1] += bfhi(v[q]); }
+        }
+        const float inv = 1.0f / (float)p.rows;
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack2bf(acc[2 * q] * inv, acc[2 * q + 1] * inv);
+        *(u32x4*)(p.out + (size_t)grp * p.D + c * 8) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // AdaptiveAvgPool3d((T, Ho, Ho)) with T unchanged. One thread per (output token, 8 channels).
 // ---------------------------------------------------------------------------------------------------------
@@ -420,6 +443,14 @@ hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s) {
     const long long total = (long long)a.B * a.T * a.S * (a.D / 8);
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(gather_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_rows(const MeanRowsArgs& a, hipStream_t s) {
+    if (a.D % 8 != 0 || a.rows <= 0) return hipErrorInvalidValue;
+    const long long total = (long long)a.groups * (a.D / 8);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -224,10 +224,12 @@ class HipEncoder:
         return (batch, 3, f, s.img, s.img) if s.pix_layout == "BCFHW" else (batch, f, 3, s.img, s.img)
 
     def forward(self, pixels: torch.Tensor, out: Optional[torch.Tensor] = None,
-                stream: Optional[torch.cuda.Stream] = None, frames: Optional[int] = None) -> torch.Tensor:
+                stream: Optional[torch.cuda.Stream] = None, frames: Optional[int] = None, select: str = "patches") -> torch.Tensor:
         """pixels in the spec's layout (fp32 or bf16, contiguous, on this device) -> [B, num_patches, D] bf16.
         `frames`: run on that many frames per video instead of the spec's count (merv_encoder_forward_frames: a
-        frame-range unit; per-frame encoders only, LanguageBind in whole clips)."""
+        frame-range unit; per-frame encoders only, LanguageBind in whole clips).
+        `select="all"`: every token of every sequence, prefix tokens first (merv_encoder_forward_select, MERV_OUT_ALL):
+        [B, sequences * (prefix + patches per sequence), D] -- the tensor the registry's other token selections slice."""
         spec = self.spec
         if pixels.device != self.device:
             raise ValueError(f"{spec.name}: pixels on {pixels.device}, encoder on {self.device}")
@@ -239,6 +241,10 @@ class HipEncoder:
         pixels = pixels.contiguous()
         f = spec.frames if frames is None else frames
         n_out = (f // spec.tubelet) * spec.s_out
+        if select == "all":
+            n_out += spec.prefix_tokens * (1 if spec.joint_space_time else f // spec.tubelet)
+        elif select != "patches":
+            raise ValueError(f"{spec.name}: select must be 'patches' or 'all', got {select!r}")
         with torch.cuda.device(self.device):  # the library launches on the CURRENT HIP device: make it this encoder's
             if out is None:
                 out = torch.empty(B, n_out, spec.dim, dtype=torch.bfloat16, device=self.device)
@@ -246,8 +252,8 @@ class HipEncoder:
                 raise ValueError(f"{spec.name}: out must be a contiguous bf16 {(B, n_out, spec.dim)} tensor")
             ws = self.workspace(B)
             s = stream if stream is not None else torch.cuda.current_stream(self.device)
-            rc = self._lib.merv_encoder_forward_frames(
-                self._handle, ptr(pixels), DT_BF16 if pixels.dtype == torch.bfloat16 else DT_F32, B, f, ptr(out), ptr(ws),
-                ws.numel(), s.cuda_stream)
+            rc = self._lib.merv_encoder_forward_select(
+                self._handle, ptr(pixels), DT_BF16 if pixels.dtype == torch.bfloat16 else DT_F32, B, f, 1 if select == "all" else 0,
+                ptr(out), ptr(ws), ws.numel(), s.cuda_stream)
         check(rc, f"merv_encoder_forward[{spec.name}]")
         return out

@@ -164,6 +164,8 @@ def from_timm_vit(sd: Mapping[str, torch.Tensor], n_layers: Optional[int] = None
         if p + "ls1.gamma" in sd:
             Lw["ls1"], Lw["ls2"] = sd[p + "ls1.gamma"], sd[p + "ls2.gamma"]
         W["layers"].append(Lw)
+    if "norm.weight" in sd:  # timm's final norm: only the bare `dinov2-video` id applies it (forward_features + token pool)
+        W["final_ln_w"], W["final_ln_b"] = sd["norm.weight"], sd["norm.bias"]
     return W
 
 

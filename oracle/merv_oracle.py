@@ -258,13 +258,63 @@ def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = Fals
     stripped, no final norm), vivit.py:100-118 (last layer + final LayerNorm, drop cls, (B,16,14,14,C)),
     siglip.py:142-151."""
     B = pix.shape[0]
+    x = encoder_hidden(pix, cfg, W, mx)
+    x = x[:, cfg.prefix_tokens:]
+    return x.reshape(B, -1, cfg.dim)
+
+
+def encoder_hidden(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = False) -> torch.Tensor:
+    """Every token of every sequence after the last block run (and the final LayerNorm where the family applies one):
+    [B * sequences, prefix + patches, D] -- hidden_states[-2] of the LanguageBind tower, timm's intermediate layer
+    (patch and prefix tokens), VivitModel.last_hidden_state."""
     x = encoder_embed(pix, cfg, W)
     for li in range(cfg.layers):
         x = encoder_block(x, cfg, W["layers"][li], mx)
     if cfg.final_ln:
         x = F.layer_norm(x, (cfg.dim,), W["final_ln_w"], W["final_ln_b"], cfg.ln_eps)
-    x = x[:, cfg.prefix_tokens:]
-    return x.reshape(B, -1, cfg.dim)
+    return x
+
+
+def select_tokens(hidden: torch.Tensor, family: str, B: int, rule: Optional[str]) -> torch.Tensor:
+    """The registry's token selections (merv/models/materialize.py:31-73) applied to encoder_hidden()'s tensor.
+    languagebind (`token` kwarg, languagebind/__init__.py:88-101): None, "average", "classemb", "noclass", "classemb-at-first".
+    dinov2 (substring of the id, dinov2_video.py:40-66,140-151): "all-tokens", "all-token-with-cls", "classemb-at-first",
+      "cls" (the bare `dinov2-video`: timm forward = final norm + class token; hidden must come from the FULL depth with final_ln).
+    vivit (vivit.py:106-118): "cls-token", "all-tokens", "all-no-cls", "all-no-cls-16frames", "classemb-at-first-16frames"."""
+    D = hidden.shape[-1]
+    if family == "languagebind":
+        v = hidden.reshape(B, -1, hidden.shape[-2], D)  # [B, F, 257, D]
+        if rule == "average":
+            v = v.mean(-2)
+        elif rule == "classemb":
+            v = v[:, :, 0, :]
+        elif rule == "noclass":
+            v = v[:, :, 1:, :]
+        elif rule == "classemb-at-first":
+            cls = v[:, :, 0, :].mean(1, keepdim=True)
+            v = torch.cat([cls, v[:, :, 1:, :].reshape(B, -1, D)], 1)
+        return v.reshape(B, -1, D)
+    if family == "dinov2":
+        npre = 5
+        patches, prefix = hidden[:, npre:], hidden[:, :npre]
+        if rule == "cls":
+            return hidden[:, 0].reshape(B, -1, D)
+        if rule == "classemb-at-first":
+            return torch.cat([prefix[:, :1].reshape(B, -1, D).mean(1, keepdim=True), patches.reshape(B, -1, D)], 1)
+        if rule == "all-token-with-cls":
+            return torch.cat([prefix[:, :1].reshape(B, -1, D), patches.reshape(B, -1, D)], 1)
+        assert rule == "all-tokens", rule
+        return patches.reshape(B, -1, D)
+    if family == "vivit":
+        if rule == "cls-token":
+            return hidden[:, 0].unsqueeze(1)
+        if rule == "all-no-cls-16frames":
+            return hidden[:, 1:].reshape(B, 16 * 14 * 14, D)
+        if rule == "all-no-cls":
+            return hidden[:, 1:].reshape(B, 16, 14, 14, D)[:, ::2].reshape(B, 8 * 14 * 14, D)
+        assert rule in ("all-tokens", "classemb-at-first-16frames"), rule  # neither branch of vivit.py:106-117 fires: unchanged
+        return hidden
+    raise ValueError(family)
 
 
 # ------------------------------------------------------------------------------------------------------------

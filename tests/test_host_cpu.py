@@ -133,10 +133,12 @@ def test_registry_keys_and_unwired_variants():
         assert k in VIDEO_BACKBONES
     with pytest.raises(ValueError, match="is not supported"):
         get_video_backbone_and_transform(["no-such-backbone"], "resize-naive", [8])
-    with pytest.raises(NotImplementedError):
-        VIDEO_BACKBONES["languagebind-video-classemb"]["cls"]("languagebind-video-classemb", "resize-naive", num_frames=8,
-                                                              weights="random", device="cpu",
-                                                              **VIDEO_BACKBONES["languagebind-video-classemb"]["kwargs"])
+    # the SigLIP ids that keep timm's attention-pooled forward (or fail inside the reference) are the only unwired ones
+    for k in ("siglip-vit-b16-224px", "siglip-vit-b16-224px-all-tokens", "siglip-vit-b16-224px-classemb-at-first"):
+        with pytest.raises(NotImplementedError, match="all-no-cls"):
+            VIDEO_BACKBONES[k]["cls"](k, "resize-naive", num_frames=8, weights="random", device="cpu", **VIDEO_BACKBONES[k]["kwargs"])
+    with pytest.raises(ValueError, match="does not exist"):
+        VIDEO_BACKBONES["languagebind-video"]["cls"]("languagebind-video", "resize-naive", num_frames=8, token="first", weights="random")
     with pytest.raises(ValueError, match="no hub access"):
         VIDEO_BACKBONES["siglip-vit-b16-224px-all-no-cls"]["cls"]("siglip-vit-b16-224px-all-no-cls", "resize-naive", num_frames=8)
 

@@ -193,3 +193,54 @@ def test_splice_hand_example():
     assert l.tolist() == [[-100, -100, -100, 5, 6, -100], [-100, -100, -100, 7, -100, -100]]
     e0, _, _ = O.splice(emb, vis, 0)
     assert torch.equal(e0[:, :2], vis)
+
+
+def test_token_selection_rules_match_the_reference_forward_bodies():
+    """oracle.select_tokens against tests/golden/token_selection.npz: the outputs of the reference's own
+    LangBindVideoBackbone / DinoV2VideoBackbone / ViVITVideoBackbone .forward bodies (languagebind/__init__.py:79-103,
+    dinov2_video.py:132-154, vivit.py:100-118) on small random hidden states (tools/make_goldens.py gen_token_selection)."""
+    import json
+    import numpy as np
+    from oracle import merv_oracle as O
+    G = Path(__file__).parent / "golden"
+    z = np.load(G / "token_selection.npz")
+    meta = json.loads((G / "token_selection.json").read_text())
+    t = lambda k: torch.from_numpy(z[k])
+    hid = t("languagebind_hidden")  # [B, F, 257, D]
+    B = hid.shape[0]
+    for token in (None, "average", "classemb", "noclass", "classemb-at-first"):
+        got = O.select_tokens(hid.reshape(-1, 257, hid.shape[-1]), "languagebind", B, token)
+        want = t(f"languagebind_{token}")
+        assert got.shape == want.shape and torch.allclose(got, want, atol=1e-6), token
+    hidden, pooled = t("dinov2_hidden"), t("dinov2_pooled")
+    for ident, rule in (("dinov2-video-all-tokens", "all-tokens"), ("dinov2-video-all-token-with-cls", "all-token-with-cls"),
+                        ("dinov2-video-classemb-at-first", "classemb-at-first")):
+        got = O.select_tokens(hidden, "dinov2", B, rule)
+        assert got.shape == t(ident).shape and torch.allclose(got, t(ident), atol=1e-6), ident
+    # the bare id: timm's forward() returns the class token after the final norm -- with `pooled` standing for that tensor's row 0
+    full = torch.cat([pooled[:, None], hidden[:, 1:]], 1)
+    assert torch.equal(O.select_tokens(full, "dinov2", B, "cls"), t("dinov2-video"))
+    last = t("vivit_hidden")
+    for ident in ("vivit-google-b-cls-token", "vivit-google-b-all-tokens", "vivit-google-b-all-no-cls",
+                  "vivit-google-b-all-no-cls-16frames", "vivit-google-b-classemb-at-first-16frames"):
+        got = O.select_tokens(last, "vivit", B, ident.replace("vivit-google-b-", ""))
+        assert got.shape == t(ident).shape and torch.equal(got, t(ident)), ident
+    # num_patches quirks of the reference properties, as merv_amd.backbones states them (no GPU: properties on a bare instance)
+    from merv_amd import backbones as BB
+    from types import SimpleNamespace as NS
+    for token in (None, "average", "classemb", "noclass", "classemb-at-first"):
+        o = object.__new__(BB.LangBindVideoBackbone)
+        torch.nn.Module.__init__(o)
+        o.token, o.num_frames = token, 4
+        assert o.num_patches == meta[f"languagebind_{token}"]["num_patches"], token
+    for ident in ("dinov2-video", "dinov2-video-all-tokens", "dinov2-video-all-token-with-cls", "dinov2-video-classemb-at-first"):
+        o = object.__new__(BB.DinoV2VideoBackbone)
+        torch.nn.Module.__init__(o)
+        o.identifier, o.num_frames, o.spec = ident, 3, NS(s_out=256)
+        assert o.num_patches == meta[ident]["num_patches"], ident
+    for ident in ("vivit-google-b-cls-token", "vivit-google-b-all-tokens", "vivit-google-b-all-no-cls",
+                  "vivit-google-b-all-no-cls-16frames", "vivit-google-b-classemb-at-first-16frames"):
+        o = object.__new__(BB.ViVITVideoBackbone)
+        torch.nn.Module.__init__(o)
+        o.video_backbone_id = ident
+        assert o.num_patches == meta[ident]["num_patches"], ident

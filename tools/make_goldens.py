@@ -397,3 +397,80 @@ def gen_preprocess():
 
 if __name__ == "__main__" and ("preprocess" in sys.argv[1:] or not sys.argv[1:]):
     gen_preprocess()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def _ref_method(path: Path, cls: str, name: str, extra_globals=None):
+    """The function object of `cls.name` defined in the reference file `path`, compiled from that file's own AST node
+    (importing the module would need timm / torchvision / the hub; the method bodies need only torch)."""
+    import ast
+    tree = ast.parse(path.read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    fn = next(n for n in node.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    fn.decorator_list = []
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"torch": torch, "Tuple": tuple, "Callable": object}
+    ns.update(extra_globals or {})
+    exec(compile(ast.fix_missing_locations(mod), str(path), "exec"), ns)
+    return ns[name]
+
+
+def gen_token_selection():
+    """The registry's token selections (materialize.py:31-73): the reference's own VideoBackbone.forward / num_patches bodies
+    (languagebind/__init__.py:79-130, dinov2_video.py:132-170, vivit.py:100-150) run on small random hidden states through a
+    stand-in `self` whose featurizer returns them. Pins oracle.select_tokens and merv_amd.backbones' selections."""
+    VB = REF / "merv/models/backbones/video"
+    NS = types.SimpleNamespace
+    g = torch.Generator().manual_seed(321)
+    out, meta = {}, {}
+    B, D = 2, 2
+    # LanguageBind: hidden_states[-2] is [B, F, 257, D]
+    F_lb = 4
+    hid = torch.randn(B, F_lb, 257, D, generator=g)
+    out["languagebind_hidden"] = hid.numpy()
+    fwd = _ref_method(VB / "languagebind/__init__.py", "LangBindVideoBackbone", "forward")
+    npatch = _ref_method(VB / "languagebind/__init__.py", "LangBindVideoBackbone", "num_patches")
+    for token in (None, "average", "classemb", "noclass", "classemb-at-first"):
+        me = NS(featurizer=lambda v, output_hidden_states: NS(hidden_states=[None, hid, None]), token=token, embed_dim=D, num_frames=F_lb)
+        y = fwd(me, torch.zeros(B, 3, F_lb, 1, 1), None)
+        out[f"languagebind_{token}"] = y.numpy()
+        meta[f"languagebind_{token}"] = {"num_patches": int(npatch(me))}
+    # DINOv2: the featurizer returns what dinov2_video.py:46-66 patched it to return for the id
+    F_d, P = 3, 256
+    hidden = torch.randn(B * F_d, 5 + P, D, generator=g)  # layer L-2, prefix tokens first
+    pooled = torch.randn(B * F_d, D, generator=g)         # timm forward(): final norm + class token (bare id)
+    out["dinov2_hidden"], out["dinov2_pooled"] = hidden.numpy(), pooled.numpy()
+    fwd = _ref_method(VB / "dinov2_video.py", "DinoV2VideoBackbone", "forward")
+    npatch = _ref_method(VB / "dinov2_video.py", "DinoV2VideoBackbone", "num_patches")
+    for ident in ("dinov2-video", "dinov2-video-all-tokens", "dinov2-video-all-token-with-cls", "dinov2-video-classemb-at-first"):
+        if "all-token-with-cls" in ident or "classemb-at-first" in ident:
+            ret = (hidden[:, 5:], hidden[:, :5])  # get_intermediate_layers(return_prefix_tokens=True) through unpack_tuple
+        elif "all-token" in ident:
+            ret = hidden[:, 5:]
+        else:
+            ret = pooled
+        me = NS(featurizer=lambda v, r=ret: r, identifier=ident, embed_dim=D, num_frames=F_d,
+                )
+        me.featurizer.patch_embed = NS(num_patches=P)
+        y = fwd(me, torch.zeros(B, F_d, 3, 1, 1), None)
+        out[ident] = y.numpy()
+        meta[ident] = {"num_patches": int(npatch(me))}
+    # ViViT: last_hidden_state [B, 3137, D]
+    last = torch.randn(B, 3137, D, generator=g)
+    out["vivit_hidden"] = last.numpy()
+    fwd = _ref_method(VB / "vivit.py", "ViVITVideoBackbone", "forward")
+    npatch = _ref_method(VB / "vivit.py", "ViVITVideoBackbone", "num_patches")
+    for ident in ("vivit-google-b-cls-token", "vivit-google-b-all-tokens", "vivit-google-b-all-no-cls",
+                  "vivit-google-b-all-no-cls-16frames", "vivit-google-b-classemb-at-first-16frames"):
+        me = NS(featurizer=lambda v: NS(last_hidden_state=last), video_backbone_id=ident,
+                huggingface_path_or_url="google/vivit-b-16x2-kinetics400")
+        y = fwd(me, torch.zeros(B, 32, 3, 1, 1), None)
+        out[ident] = y.numpy()
+        meta[ident] = {"num_patches": int(npatch(me))}
+    np.savez_compressed(OUT / "token_selection.npz", **out)
+    (OUT / "token_selection.json").write_text(json.dumps(meta, indent=1))
+    print("token_selection:", {k: tuple(v.shape) for k, v in out.items() if "hidden" not in k and "pooled" not in k})
+
+
+if __name__ == "__main__" and ("token_selection" in sys.argv[1:] or not sys.argv[1:]):
+    gen_token_selection()
