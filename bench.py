@@ -280,6 +280,25 @@ def main():
         up = dpath.synth_unit_pixels(seed=1234)
         return (lambda: dpath.forward(up)), dpath
 
+    def units_equal_local(st, dp_, seed=1234):
+        """Runs the placed step once more and compares the fused tokens / fusion weights this rank ends up with against the same
+        videos pushed through the plain single-GPU path here (unit pixels are a function of (seed, encoder, video), so every rank
+        can rebuild whole videos). True only if every rank finds them bit-equal."""
+        fused, w = st()
+        fused, w = fused.clone(), w.clone()  # the placed path fuses into the local path's persistent buffers
+        n = fused.shape[0]
+        v0 = 0 if dp_.replicate else rank * n
+        pix = []
+        for e, sp in enumerate(specs):
+            vids = [torch.randn(sp.pixel_shape(1), generator=torch.Generator(device=device).manual_seed(seed * 1000003 + e * 10007 + v),
+                                device=device).to(torch.bfloat16) for v in range(v0, v0 + n)]
+            pix.append(torch.cat(vids, 0))
+        ref_f, ref_w = path.forward(pix)
+        ok = torch.tensor([int(torch.equal(ref_f, fused) and torch.equal(ref_w, w))], device=device)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item())
+
     headline_units = multi and args.parallelism == "units"
     if headline_units:
         step, dpath = make_units_step(args.exchange)
@@ -302,11 +321,13 @@ def main():
                     el = timed(st)
                 multi_gpu[f"units_{ex}_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / el, 1)
                 multi_gpu[f"units_{ex}_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
+                multi_gpu[f"units_{ex}_bit_equal_to_single_gpu_path"] = units_equal_local(st if not (headline_units and ex == args.exchange) else step, dp_)
             # latency placement: ONE video spread over all ranks (LanguageBind by clip, DINOv2 / SigLIP by frame
             # ranges, ViViT whole), projected rows all-gathered, every rank fuses (so each holds the tokens for its prefill)
             st, dp_ = make_units_step("all_gather", n_videos=1, replicate=True)
             el = timed(st)
             multi_gpu["one_video_latency_ms"] = round(el / args.steps * 1e3, 3)
+            multi_gpu["one_video_bit_equal_to_single_gpu_path"] = units_equal_local(st, dp_)
             multi_gpu["one_video_plan"] = dp_.describe_plan()
             multi_gpu["one_video_exchange_bytes_per_rank"] = dp_.exchange_bytes_per_rank()
             if world == 4:  # the literal configs[2] placement for comparison: encoder e on rank e

@@ -161,6 +161,20 @@ class DistributedVisualPath:
     def forward(self, unit_pixels: Sequence[torch.Tensor]):
         """unit_pixels[i] = pixels of self.my_units[i] (encoder e's layout, videos v0..v1, frames f0..f1 only).
         Returns (fused [B, T, llm], weights [B, E]) for the videos this rank fuses."""
+        send = self.produce(unit_pixels)
+        # ---- one collective
+        if self.exchange == "all_to_all":
+            recv = self._buf("recv", self.E * self.B * self.T)
+            dist.all_to_all_single(recv[: self.E * self.B * self.T], send[: self.rows_sent[self.rank]],
+                                   output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits, group=self.group)
+        else:
+            recv = self._buf("gathered", self.world * self.max_rows)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        return self.finish(recv)
+
+    def produce(self, unit_pixels: Sequence[torch.Tensor]) -> torch.Tensor:
+        """This rank's units through encoder + projector, their projected rows packed in send order (the collective's input:
+        rows_sent[rank] rows for all_to_all, padded to max_rows for all_gather)."""
         local = self.local
         if len(unit_pixels) != len(self.my_units):
             raise ValueError(f"expected {len(self.my_units)} unit pixel tensors, got {len(unit_pixels)}")
@@ -199,15 +213,11 @@ class DistributedVisualPath:
             n = self.rows(c)
             send[off:off + n].copy_(produced[c])
             off += n
-        # ---- one collective
-        if self.exchange == "all_to_all":
-            recv = self._buf("recv", self.E * self.B * T)
-            dist.all_to_all_single(recv[: self.E * self.B * T], send[: self.rows_sent[self.rank]],
-                                   output_split_sizes=self.recv_splits, input_split_sizes=self.send_splits, group=self.group)
-        else:
-            recv = self._buf("gathered", self.world * self.max_rows)
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        # ---- scatter the chunks of my videos into V_e [B, T, llm]
+        return send
+
+    def finish(self, recv: torch.Tensor):
+        """The collective's output -> the chunks of my videos scattered into V_e [B, T, llm] -> fusion."""
+        local, T, C = self.local, self.T, self.C
         V = [self._buf(f"V{e}", self.B * T).view(self.B, T, C) for e in range(self.E)]
         v_base = 0 if self.replicate else self.rank * self.B
         for c, at in self.recv_at:
