@@ -6,6 +6,7 @@ import json
 import re
 from pathlib import Path
 
+import numpy as np
 import pytest
 import torch
 
@@ -350,3 +351,80 @@ def test_load_video_frame_directories(tmp_path):
     assert cfg.num_frames == cfg["num_frames"] == [16, 16, 32, 16] and cfg.model_id == "merv-full"
     with pytest.raises(AttributeError):
         cfg.no_such_field
+
+
+def test_sampler_matches_numpy_on_random_videos():
+    """The reference's two call sites are `np.linspace(a, b, n, dtype=int)` (datasets.py:131-141); numpy is on every box, so the
+    C sampler is compared with it directly on 3000 random (N, fps, clip window | end_frame, n) tuples beside the committed
+    goldens: bit-exact int64 indices, including fractional NTSC rates, windows past the end and fewer frames than samples."""
+    import math
+    from merv_amd.sampler import frame_indices
+    rng = np.random.RandomState(20260)
+    rates = [23.976023976023978, 24.0, 25.0, 29.97, 29.97002997002997, 30.0, 50.0, 59.94, 59.94005994005994, 60.0, 12.5, 15.0, 7.0]
+    for it in range(3000):
+        N = int(rng.randint(1, 40000)) if it % 7 else int(rng.randint(1, 40))
+        fps = float(rng.choice(rates)) if it % 5 else float(rng.uniform(1.0, 120.0))
+        n = int(rng.choice([1, 2, 4, 8, 12, 16, 32, 33, 64]))
+        total = N / fps
+        mode = it % 3
+        if mode == 0:
+            s, e, ef = float(rng.uniform(0, total * 0.7)), None, None
+            e = float(rng.uniform(s + 0.01, total * 1.2))
+            want = np.linspace(s * fps, min(N - 1, e * fps - 1), n, dtype=int)
+        elif mode == 1:
+            s, e, ef = 0.0, None, None
+            want = np.linspace(s * fps, min(N - 1, total * fps - 1), n, dtype=int)
+        else:
+            s, e, ef = 0.0, None, int(rng.randint(0, N + 100))
+            want = np.linspace(0, min(N - 1, ef), n, dtype=int)
+        got = frame_indices(N, fps, s, e, n, ef)
+        assert got == [int(i) for i in want], (N, fps, s, e, n, ef)
+
+
+def test_sampler_under_address_and_ub_sanitizers(tmp_path):
+    """The host-side C++ of the library (the frame-index sampler) built with -fsanitize=address,undefined by gcc and driven
+    over every committed golden case plus the error paths: no report, same indices. (GPU sanitizers are not available on
+    the pool; this is the CPU build the task statement allows.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    cases = json.loads((G / "frame_indices.json").read_text())
+    rows = []
+    for c in cases:
+        s = "NAN" if c["clip_start_sec"] is None or (isinstance(c["clip_start_sec"], float) and c["clip_start_sec"] != c["clip_start_sec"]) else repr(float(c["clip_start_sec"]))
+        e = "NAN" if c["clip_end_sec"] is None or (isinstance(c["clip_end_sec"], float) and c["clip_end_sec"] != c["clip_end_sec"]) else repr(float(c["clip_end_sec"]))
+        ef = -1 if c["end_frame"] is None else int(c["end_frame"])
+        rows.append("{%dLL, %r, %s, %s, %dLL, %d}" % (c["N"], float(c["fps"]), s, e, ef, c["num_frames"]))
+    src = tmp_path / "h.cpp"
+    src.write_text('''
+#include <cstdio>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+#include "%s/include/merv_hip.h"
+extern "C" void merv_set_error(const char*) {}
+struct C { long long N; double fps, s, e; long long ef; int n; };
+int main() {
+    const C cases[] = {%s};
+    for (const C& c : cases) {
+        std::vector<int64_t> ids(c.n > 0 ? c.n : 1);
+        if (merv_frame_indices(c.N, c.fps, c.s, c.e, c.ef, c.n, ids.data())) return 2;
+        for (int i = 0; i < c.n; ++i) printf("%%lld ", (long long)ids[i]);
+        printf("\\n");
+    }
+    int64_t one; int32_t idx[64], cnt;
+    if (!merv_frame_indices(0, 30.0, 0.0, NAN, -1, 1, &one)) return 3;      // empty video is an error
+    if (!merv_frame_indices(10, 30.0, 0.0, NAN, -1, 1, nullptr)) return 4;  // null output is an error
+    if (merv_temporal_subsample(32, 32, 12, idx, &cnt) || cnt != 16) return 5;
+    if (!merv_temporal_subsample(32, 16, 32, idx, &cnt)) return 6;          // step 0 is an error
+    return 0;
+}
+''' % (ROOT, ", ".join(rows)))
+    exe = tmp_path / "h"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    str(src), str(ROOT / "merv_amd/csrc/sampler.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env={"ASAN_OPTIONS": "detect_leaks=1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [[int(x) for x in line.split()] for line in out.stdout.strip().split("\n")]
+    assert got == [c["ids"] for c in cases]
