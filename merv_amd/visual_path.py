@@ -196,7 +196,10 @@ class MervVisualPath:
         graph removes most of the launch overhead; at batch 8 it is within noise."""
         self.forward(pixels)  # warm-up outside the capture: kernel attributes, workspaces, persistent buffers
         torch.cuda.synchronize(self.device)
-        static = [p.clone() for p in pixels]
+        with torch.inference_mode(False):  # a capture made under inference_mode must stay writable by later, ordinary callers
+            static = [torch.empty(p.shape, dtype=p.dtype, device=p.device) for p in pixels]
+        for dst, src in zip(static, pixels):
+            dst.copy_(src)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             fused, weights = self.forward(static)
