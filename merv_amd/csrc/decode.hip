@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
 constexpr int GEMV_ROWS = 2;   // rows per wave (x chunk reused across them)
 constexpr int GEMV_WAVES = 4;  // waves per block
 
-template <int NW_MATS, int UN>  // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x)
+template <int NW_MATS, int UN, bool NORM>  // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     // flight per lane before the first use. Every trip is a full batch: chunks past the row's end are clamped to a valid
     // address and meet x = 0 (a remainder loop of single loads costs one memory round trip per iteration: 3 us of the
     // K = 11008 launch).
-    u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[UN];
+    u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[NORM ? UN : 1];
     auto issue = [&](int c) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
 #pragma unroll
                 for (int r = 0; r < GEMV_ROWS; ++r) wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + cu * 8));
             xv[u] = *(const u32x4*)(p.x + cu * 8);
-            nv[u] = p.norm_w ? *(const u32x4*)(p.norm_w + cu * 8) : u32x4{0u, 0u, 0u, 0u};
+            if constexpr (NORM) nv[u] = *(const u32x4*)(p.norm_w + cu * 8);
         }
     };
     // fused RMSNorm: the wave reduces mean(x^2) over the whole input once (8 KB, L2-resident) BEHIND the first trip's weight
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     int c = lane;
     if (c < nchunk) issue(c);
     float rstd = 0.f;
-    if (p.norm_w) {
+    if constexpr (NORM) {
         float ss = 0.f;
         for (int cc = lane; cc < nchunk; cc += 64) {
             float f[8];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
         for (int u = 0; u < UN; ++u) {
             float xf[8];
             unpack8f(xv[u], xf);
-            if (p.norm_w) {
+            if constexpr (NORM) {
                 float wn[8];
                 unpack8f(nv[u], wn);
 #pragma unroll
@@ -464,9 +464,17 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
             return hipErrorInvalidValue;
     }
     dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
-    // UN (chunks per lane per trip), step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms, 8: 4.60 ms
-    if (a.W2) hipLaunchKernelGGL((gemv_kernel<2, 4>), grid, dim3(GEMV_WAVES * 64), 0, s, a);
-    else hipLaunchKernelGGL((gemv_kernel<1, 4>), grid, dim3(GEMV_WAVES * 64), 0, s, a);
+    // UN (chunks per lane per trip), step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms, 8: 4.60 ms (284 registers
+    // with the norm arrays live; without them hipcc serialises the 16 loads again: no gain); the norm is a template flag: 3.21 ms
+    const dim3 blk(GEMV_WAVES * 64);
+    if (a.W2) {
+        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, 4, true>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((gemv_kernel<2, 4, false>), grid, blk, 0, s, a);
+    } else if (a.norm_w) {
+        hipLaunchKernelGGL((gemv_kernel<1, 4, true>), grid, blk, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<1, 4, false>), grid, blk, 0, s, a);
+    }
     return hipGetLastError();
 }
 
