@@ -334,6 +334,11 @@ size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
+/* The attention step of timm's AttentionPoolLatent (global_pool='map': what the SigLIP ids without `all-no-cls` return,
+ * siglip.py:46-63): one learnt query per head against every token of a frame. kv [nseq*ntok, 2*D] bf16 = [k | v] rows (the kv
+ * Linear's output), q [D] fp32 = q Linear of the latent, out [nseq, D] bf16; D = heads * 64, ntok <= 1024. */
+int merv_map_pool_attention(const void *kv, const float *q, void *out, int32_t nseq, int32_t ntok, int32_t heads, float scale,
+                            void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
     "merv_encoder_forward_frames": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "merv_encoder_forward_select": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "merv_mean_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, C.c_int64, _vp]),
+    "merv_map_pool_attention": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "merv_projector_forward": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "merv_fusion_workspace_floats": (_sz, [_i32, _i32, _i32]),
     "merv_fusion_forward": (C.c_int, [C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -6,10 +6,10 @@ Differences from the reference, all forced by this environment (no network, no t
   * weights are not downloaded in __init__; pass `weights=` (an upstream state dict of the matching family or a
     canonical dict, see merv_amd/weights.py) or `weights="random"` for seeded synthetic parameters;
   * every token selection of the LanguageBind / DINOv2 / ViViT registry keys is wired (a slice, a concatenation or a mean --
-    merv_mean_rows -- of the encoder's full token tensor, merv_encoder_forward_select); of the SigLIP keys only
-    `siglip-vit-b16-224px-all-no-cls`: the others return timm's attention-pooled (MAP head) feature per frame
-    (siglip.py:46-63 leaves the timm forward in place unless the id says all-no-cls) or, for `classemb-at-first`, fail inside
-    the reference itself (a tuple is reshaped, siglip.py:148-149) -- they raise NotImplementedError when constructed;
+    merv_mean_rows -- of the encoder's full token tensor, merv_encoder_forward_select); the B/16-224 SigLIP keys without
+    `all-no-cls` return timm's attention-pooled (MAP head) feature per frame (siglip.py:46-63 leaves the timm forward in place),
+    built here from the library's GEMM / LayerNorm kernels and merv_map_pool_attention; `siglip-...-classemb-at-first` fails
+    inside the reference itself (a tuple is reshaped, siglip.py:148-149) and raises NotImplementedError when constructed;
   * `video_transform` is the GPU implementation of the reference's CPU PIL / torchvision pipelines
     (merv_amd/preprocess.py: Pillow-bit-exact resize + ToTensor + Normalize; LanguageBind's torch pipeline with the
     random flip made an explicit, default-off switch): it takes load_video()'s uint8 [F,3,H,W] tensor on the device.
@@ -137,6 +137,15 @@ def random_weights(spec: EncoderSpec, seed: int, device="cpu", bf16_exact: bool 
                 if k in d:
                     d[k] = d[k].to(torch.bfloat16).float()
     return out
+
+
+def random_map_pool_weights(D: int, mlp: int, seed: int) -> Dict:
+    """Seeded synthetic parameters of the attention-pooling head (timm AttentionPoolLatent layout, see weights.from_timm_attn_pool)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *shape, std=0.02: torch.randn(*shape, generator=g) * std
+    return {"latent": rn(1, D, std=0.5), "q_w": rn(D, D, std=D**-0.5), "q_b": rn(D), "kv_w": rn(2 * D, D, std=D**-0.5), "kv_b": rn(2 * D),
+            "proj_w": rn(D, D, std=D**-0.5), "proj_b": rn(D), "norm_w": 1 + rn(D, std=0.1), "norm_b": rn(D, std=0.1),
+            "fc1_w": rn(mlp, D, std=D**-0.5), "fc1_b": rn(mlp), "fc2_w": rn(D, mlp, std=mlp**-0.5), "fc2_b": rn(D)}
 
 
 def weights_to(W: Dict, device) -> Dict:
@@ -287,19 +296,76 @@ class ViVITVideoBackbone(VideoBackbone):
 
 
 class SiglipVideoBackbone(VideoBackbone):
-    """siglip.py:35-174 -- timm vit_base_patch16_siglip_224, get_intermediate_layers(n={L-2}), no class token."""
+    """siglip.py:35-174 -- timm vit_base_patch16_siglip_224. `*-all-no-cls`: get_intermediate_layers(n={L-2}), every patch token.
+    Every other id keeps timm's forward() (siglip.py:46-63 only patches it for all-no-cls / classemb-at-first): all L blocks, the
+    final norm and the attention-pooling head (global_pool='map'), one feature per frame."""
 
     def __init__(self, video_backbone_id: str, image_resize_strategy: str, default_image_size: int = 224,
-                 num_frames: int = 8, weights=None, device="cuda:0", layers: int = 11, ln_fold: bool = True) -> None:
+                 num_frames: int = 8, weights=None, device="cuda:0", layers: Optional[int] = None, ln_fold: bool = True,
+                 pool_weights=None) -> None:
         super().__init__(video_backbone_id, image_resize_strategy, default_image_size, num_frames)
-        if video_backbone_id != "siglip-vit-b16-224px-all-no-cls":
-            raise NotImplementedError(
-                f"`{video_backbone_id}`: only `siglip-vit-b16-224px-all-no-cls` is wired. Ids without `all-no-cls` keep timm's forward() "
-                "(siglip.py:46-63): the attention-pooled MAP-head feature of every frame, which this path does not implement; "
-                "`classemb-at-first` reshapes a tuple in the reference itself (siglip.py:148-149)")
+        if not video_backbone_id.startswith("siglip-vit-b16-224px"):
+            raise NotImplementedError(f"`{video_backbone_id}`: only the B/16 224 px tower is wired")
+        if "classemb-at-first" in video_backbone_id:
+            raise NotImplementedError(f"`{video_backbone_id}` fails inside the reference itself: get_intermediate_layers(return_prefix_tokens="
+                                      "True) hands forward() a tuple, which it reshapes (siglip.py:56-63,148-149)")
+        self.class_token = "all-no-cls" not in video_backbone_id  # siglip.py:46-49 (its name for "pooled output")
+        if layers is None:
+            layers = 12 if self.class_token else 11
         spec = EncoderSpec("siglip", 768, 12, 3072, layers, 16, 1, default_image_size, num_frames, "BFCHW", 0, False, False,
-                           False, False, 0, "gelu_erf", 1e-6)
+                           self.class_token, False, 0, "gelu_erf", 1e-6)
         self._build(spec, weights, device, lambda sd: W.from_timm_vit(sd, n_layers=layers), ln_fold)
+        self.pool_weights = None
+        if self.class_token:
+            if pool_weights is None and isinstance(weights, dict) and any(k.endswith("attn_pool.latent") for k in weights):
+                pool_weights = weights  # an upstream timm state dict carries attn_pool.* beside the blocks
+            if isinstance(pool_weights, dict) and "latent" in pool_weights:
+                pw = pool_weights
+            elif isinstance(pool_weights, dict):
+                pw = W.from_timm_attn_pool(pool_weights)
+            elif isinstance(weights, str) and weights == "random":
+                pw = random_map_pool_weights(spec.dim, spec.mlp_dim, seed=spec.dim + 7)
+            else:
+                raise ValueError(f"`{video_backbone_id}` returns the attention-pooled feature: pass pool_weights=<timm attn_pool.* state "
+                                 "dict or MAP-head dict> (nothing is silently random)")
+            self.pool_weights = {k: v.detach().float().cpu() for k, v in pw.items()}  # canonical fp32 copy (inspection / checks)
+            dev = torch.device(device)
+            bf = lambda k: self.pool_weights[k].to(dev, torch.bfloat16).contiguous()
+            f32 = lambda k: self.pool_weights[k].to(dev, torch.float32).contiguous()
+            self._pool = {"kv_w": bf("kv_w"), "kv_b": f32("kv_b"), "proj_w": bf("proj_w"), "proj_b": f32("proj_b"),
+                          "norm_w": f32("norm_w"), "norm_b": f32("norm_b"), "fc1_w": bf("fc1_w"), "fc1_b": f32("fc1_b"),
+                          "fc2_w": bf("fc2_w"), "fc2_b": f32("fc2_b"),
+                          # the query does not depend on the input: q Linear of the latent, once
+                          "q": torch.nn.functional.linear(self.pool_weights["latent"], self.pool_weights["q_w"],
+                                                          self.pool_weights["q_b"]).reshape(-1).to(dev, torch.float32).contiguous()}
+
+    def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """siglip.py:142-151."""
+        if not self.class_token:
+            return self.featurizer.forward(video_values)
+        from . import ops
+        from ._lib import check, ptr
+        B, D, S = video_values.shape[0], self.spec.dim, self.spec.s_out
+        x = self.featurizer.forward(video_values, select="all").view(-1, D)  # [B*F*196, D]: blocks + final norm
+        nseq = x.shape[0] // S
+        P = self._pool
+        with torch.cuda.device(x.device):
+            kv = ops.gemm(x, P["kv_w"], P["kv_b"])  # [B*F*196, 2D]
+            att = torch.empty(nseq, D, dtype=torch.bfloat16, device=x.device)
+            check(self.featurizer._lib.merv_map_pool_attention(ptr(kv), ptr(P["q"]), ptr(att), nseq, S, self.spec.heads, 64**-0.5,
+                                                               torch.cuda.current_stream(x.device).cuda_stream), "merv_map_pool_attention")
+            y = ops.gemm(att, P["proj_w"], P["proj_b"])
+            h = ops.gemm(ops.layernorm(y, P["norm_w"], P["norm_b"], 1e-6), P["fc1_w"], P["fc1_b"], act="gelu_erf")
+            out = ops.gemm(h, P["fc2_w"], P["fc2_b"], res=y)  # x + mlp(norm(x)); latent_len = 1: token 0 is the row
+        return out.view(B, -1, D)
+
+    @property
+    def num_patches(self) -> int:  # siglip.py:161-166
+        return self.num_frames if self.class_token else self.num_frames * self.spec.s_out
+
+    @property
+    def spatial_resolution(self) -> int:
+        return self.num_patches // self.num_frames
 
     @property
     def default_video_resolution(self) -> Tuple[int, int, int, int]:

@@ -863,3 +863,13 @@ extern "C" int merv_mean_rows(const void* x, void* out, int32_t groups, int32_t 
     MERV_HIP(launch_mean_rows(a, (hipStream_t)stream_));
     return 0;
 }
+
+extern "C" int merv_map_pool_attention(const void* kv, const float* q, void* out, int32_t nseq, int32_t ntok, int32_t heads,
+                                       float scale, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(kv && q && out, "merv_map_pool_attention: null argument");
+    MERV_CHECK(nseq >= 0 && ntok > 0 && ntok <= 1024 && heads > 0, "merv_map_pool_attention: bad geometry (head dim 64, at most 1024 tokens)");
+    MapPoolArgs a{(const bf16_t*)kv, q, (bf16_t*)out, nseq, ntok, heads, scale};
+    MERV_HIP(launch_map_pool(a, (hipStream_t)stream_));
+    return 0;
+}

@@ -167,6 +167,17 @@ struct GatherTokensArgs {
 };
 hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s);
 
+// Attention pooling with ONE fixed query per head (timm AttentionPoolLatent / SigLIP "MAP" head): per sequence n and head h,
+// out[n][h*64 + d] = sum_s softmax_s(scale * q[h*64:] . k[n][s][h*64:]) v[n][s][h*64 + d]; kv rows hold [k (D) | v (D)] bf16.
+struct MapPoolArgs {
+    const bf16_t* kv;  // [nseq * ntok, 2 * D]
+    const float* q;    // [D] the projected latent query
+    bf16_t* out;       // [nseq, D]
+    int nseq, ntok, heads;
+    float scale;       // 1 / sqrt(64)
+};
+hipError_t launch_map_pool(const MapPoolArgs& a, hipStream_t s);
+
 // out[g][:] = bf16(mean_r x[g][r][:]), fp32 accumulation (torch's mean on a bf16 tensor). x [groups, rows, D] with a row stride
 // of D and a group stride of group_stride rows.
 struct MeanRowsArgs {

@@ -215,6 +215,57 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(GatherTokensArgs p) 
     }
 }
 
+// Attention pooling with one fixed query per head (MapPoolArgs). One block per (sequence, head), 256 threads: thread t scores
+// keys t, t + 256, ... (its own 128-byte k slice against the query in registers), the block reduces max and sum through LDS,
+// then 4 groups of 64 threads (one output dim each) walk the keys and the groups are summed. fp32 softmax and accumulation.
+__global__ __launch_bounds__(256) void map_pool_kernel(MapPoolArgs p) {
+    constexpr int HD = 64, MAX_S = 1024;
+    __shared__ float sc[MAX_S];
+    __shared__ float red[8];
+    __shared__ float part[4][HD];
+    const int n = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.heads * HD;
+    const bf16_t* base = p.kv + (size_t)n * p.ntok * 2 * D + h * HD;
+    float q[HD];
+#pragma unroll
+    for (int i = 0; i < HD; ++i) q[i] = p.q[h * HD + i];
+    float mx = -INFINITY;
+    for (int s = tid; s < p.ntok; s += 256) {
+        const bf16_t* k = base + (size_t)s * 2 * D;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const u32x4 v = *(const u32x4*)(k + c * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d = fmaf(bflo(v[j]), q[c * 8 + 2 * j], fmaf(bfhi(v[j]), q[c * 8 + 2 * j + 1], d));
+        }
+        d *= p.scale;
+        sc[s] = d;
+        mx = fmaxf(mx, d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int s = tid; s < p.ntok; s += 256) {
+        const float e = __expf(sc[s] - mx);
+        sc[s] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    sum = red[4] + red[5] + red[6] + red[7];
+    float acc = 0.f;
+    for (int s = wave; s < p.ntok; s += 4) acc = fmaf(sc[s], bf2f(base[(size_t)s * 2 * D + D + lane]), acc);
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (tid < HD) p.out[(size_t)n * D + h * HD + tid] = f2bf((part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) / sum);
+}
+
 // Mean over the rows of each group (token-selection variants of the backbones: per-frame mean over all tokens,
 // mean of the per-frame class tokens). One thread per (group, 8 channels); the row loop reads 16 B per lane, coalesced over c.
 __global__ __launch_bounds__(256) void mean_rows_kernel(MeanRowsArgs p) {
@@ -443,6 +494,13 @@ hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s) {
     const long long total = (long long)a.B * a.T * a.S * (a.D / 8);
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(gather_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_map_pool(const MapPoolArgs& a, hipStream_t s) {
+    if (a.heads <= 0 || a.ntok <= 0 || a.ntok > 1024) return hipErrorInvalidValue;
+    if (a.nseq <= 0) return hipSuccess;
+    hipLaunchKernelGGL(map_pool_kernel, dim3(a.heads, a.nseq), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

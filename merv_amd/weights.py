@@ -169,6 +169,27 @@ def from_timm_vit(sd: Mapping[str, torch.Tensor], n_layers: Optional[int] = None
     return W
 
 
+def from_timm_attn_pool(sd: Mapping[str, torch.Tensor]) -> Dict:
+    """timm AttentionPoolLatent (`attn_pool.*` of vit_base_patch16_siglip_224, global_pool='map') -> the MAP-head dict."""
+    sd = _strip(sd, ())
+    p = "attn_pool."
+    return {"latent": sd[p + "latent"].reshape(1, -1), "q_w": sd[p + "q.weight"], "q_b": sd[p + "q.bias"],
+            "kv_w": sd[p + "kv.weight"], "kv_b": sd[p + "kv.bias"], "proj_w": sd[p + "proj.weight"], "proj_b": sd[p + "proj.bias"],
+            "norm_w": sd[p + "norm.weight"], "norm_b": sd[p + "norm.bias"], "fc1_w": sd[p + "mlp.fc1.weight"],
+            "fc1_b": sd[p + "mlp.fc1.bias"], "fc2_w": sd[p + "mlp.fc2.weight"], "fc2_b": sd[p + "mlp.fc2.bias"]}
+
+
+def from_hf_siglip_head(sd: Mapping[str, torch.Tensor]) -> Dict:
+    """transformers SiglipMultiheadAttentionPoolingHead (`head.*`): nn.MultiheadAttention's packed in_proj = [q; k; v] rows."""
+    g = lambda k: next(v for n, v in sd.items() if n.endswith("head." + k) or n == k)
+    D = g("probe").shape[-1]
+    w, b = g("attention.in_proj_weight"), g("attention.in_proj_bias")
+    return {"latent": g("probe").reshape(1, D), "q_w": w[:D], "q_b": b[:D], "kv_w": w[D:], "kv_b": b[D:],
+            "proj_w": g("attention.out_proj.weight"), "proj_b": g("attention.out_proj.bias"), "norm_w": g("layernorm.weight"),
+            "norm_b": g("layernorm.bias"), "fc1_w": g("mlp.fc1.weight"), "fc1_b": g("mlp.fc1.bias"), "fc2_w": g("mlp.fc2.weight"),
+            "fc2_b": g("mlp.fc2.bias")}
+
+
 def from_hf_dinov2(sd: Mapping[str, torch.Tensor], n_layers: Optional[int] = None) -> Dict:
     """HF Dinov2WithRegistersModel: emb = cat(cls, patches) + pos, registers inserted after cls without position."""
     sd = _strip(sd, ())

@@ -275,6 +275,22 @@ def encoder_hidden(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = False
     return x
 
 
+def map_pool(x: torch.Tensor, Pw: Dict[str, torch.Tensor], heads: int, act: str = "gelu_erf", eps: float = 1e-6) -> torch.Tensor:
+    """The attention-pooling ("MAP") head timm's forward() ends with on the SigLIP towers (global_pool='map':
+    AttentionPoolLatent, timm 0.9.10 -- ABSENT here, timm parity unpinned; the same head as transformers'
+    SiglipMultiheadAttentionPoolingHead, on whose outputs this function is pinned, tests/golden/siglip_pool.npz): a learnt
+    latent query attends over the final-norm tokens of a frame, out-projection, x + mlp(norm(x)), token 0.
+    x [N, S, D] -> [N, D]. Pw: latent [1, D], q_w/q_b [D, D], kv_w/kv_b [2D, D], proj_w/b, norm_w/b, fc1_w/b, fc2_w/b."""
+    N, S, D = x.shape
+    hd = D // heads
+    q = F.linear(Pw["latent"], Pw["q_w"], Pw["q_b"]).reshape(1, heads, 1, hd).expand(N, -1, -1, -1)
+    kv = F.linear(x, Pw["kv_w"], Pw["kv_b"]).reshape(N, S, 2, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax((q @ kv[0].transpose(-1, -2)) * hd**-0.5, dim=-1) @ kv[1]  # [N, heads, 1, hd]
+    y = F.linear(att.transpose(1, 2).reshape(N, D), Pw["proj_w"], Pw["proj_b"])
+    h = F.layer_norm(y, (D,), Pw["norm_w"], Pw["norm_b"], eps)
+    return y + F.linear(act_fn(act, F.linear(h, Pw["fc1_w"], Pw["fc1_b"])), Pw["fc2_w"], Pw["fc2_b"])
+
+
 def select_tokens(hidden: torch.Tensor, family: str, B: int, rule: Optional[str]) -> torch.Tensor:
     """The registry's token selections (merv/models/materialize.py:31-73) applied to encoder_hidden()'s tensor.
     languagebind (`token` kwarg, languagebind/__init__.py:88-101): None, "average", "classemb", "noclass", "classemb-at-first".

@@ -65,3 +65,43 @@ def test_mean_rows_is_torch_mean_of_a_bf16_tensor(dev):
         ref = x.float().mean(1)
         assert (out.float() - ref).abs().max() <= ref.abs().max() * 2**-8
         assert rel_l2(out, ref) < 3e-3
+
+
+@pytest.mark.parametrize("ident", ["siglip-vit-b16-224px", "siglip-vit-b16-224px-all-tokens"])
+def test_pooled_siglip_ids(dev, ident):
+    """The SigLIP ids that keep timm's forward(): blocks + final norm + attention-pooling head, one feature per frame
+    (siglip.py:46-63,142-151), against oracle.map_pool (pinned on transformers' SigLIP pooling head) of the oracle's hidden states."""
+    from oracle import merv_oracle as O
+    from oracle.parity import spec_to_cfg
+    from merv_amd.backbones import VIDEO_BACKBONES, random_weights
+    entry = VIDEO_BACKBONES[ident]
+    bb = entry["cls"](ident, "resize-naive", num_frames=3, weights="random", device=dev, layers=2, **entry["kwargs"])
+    spec = bb.spec
+    assert spec.final_ln and bb.num_patches == 3 and bb.spatial_resolution == 1
+    W = random_weights(spec, seed=spec.dim + spec.frames)
+    B = 2
+    pix = torch.randn(spec.pixel_shape(B), generator=torch.Generator().manual_seed(6))
+    hidden = O.encoder_hidden(pix, spec_to_cfg(spec), W)  # [B*3, 196, 768] after the final norm
+    ref = O.map_pool(hidden, bb.pool_weights, heads=spec.heads).reshape(B, 3, spec.dim)
+    out = bb(pix.to(dev), None)
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16
+    assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
+
+
+def test_map_pool_attention_kernel(dev):
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for nseq, S, heads in [(6, 196, 12), (1, 1, 2), (3, 1000, 4)]:
+        D = heads * 64
+        kv = torch.randn(nseq * S, 2 * D, generator=g).to(torch.bfloat16).to(dev)
+        q = (torch.randn(D, generator=g) * 2).to(dev)
+        out = torch.empty(nseq, D, dtype=torch.bfloat16, device=dev)
+        check(lib.merv_map_pool_attention(ptr(kv), ptr(q), ptr(out), nseq, S, heads, 0.125, torch.cuda.current_stream(dev).cuda_stream), "map")
+        k = kv[:, :D].float().view(nseq, S, heads, 64)
+        v = kv[:, D:].float().view(nseq, S, heads, 64)
+        p = torch.softmax(torch.einsum("nshd,hd->nhs", k, q.view(heads, 64)) * 0.125, -1)
+        ref = torch.einsum("nhs,nshd->nhd", p, v).reshape(nseq, D)
+        assert rel_l2(out, ref) < 4e-3, (nseq, S, heads, rel_l2(out, ref))

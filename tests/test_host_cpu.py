@@ -134,10 +134,10 @@ def test_registry_keys_and_unwired_variants():
         assert k in VIDEO_BACKBONES
     with pytest.raises(ValueError, match="is not supported"):
         get_video_backbone_and_transform(["no-such-backbone"], "resize-naive", [8])
-    # the SigLIP ids that keep timm's attention-pooled forward (or fail inside the reference) are the only unwired ones
-    for k in ("siglip-vit-b16-224px", "siglip-vit-b16-224px-all-tokens", "siglip-vit-b16-224px-classemb-at-first"):
-        with pytest.raises(NotImplementedError, match="all-no-cls"):
-            VIDEO_BACKBONES[k]["cls"](k, "resize-naive", num_frames=8, weights="random", device="cpu", **VIDEO_BACKBONES[k]["kwargs"])
+    # the one key that cannot be wired: it fails inside the reference itself
+    k = "siglip-vit-b16-224px-classemb-at-first"
+    with pytest.raises(NotImplementedError, match="fails inside the reference"):
+        VIDEO_BACKBONES[k]["cls"](k, "resize-naive", num_frames=8, weights="random", device="cpu", **VIDEO_BACKBONES[k]["kwargs"])
     with pytest.raises(ValueError, match="does not exist"):
         VIDEO_BACKBONES["languagebind-video"]["cls"]("languagebind-video", "resize-naive", num_frames=8, token="first", weights="random")
     with pytest.raises(ValueError, match="no hub access"):

@@ -244,3 +244,17 @@ def test_token_selection_rules_match_the_reference_forward_bodies():
         torch.nn.Module.__init__(o)
         o.video_backbone_id = ident
         assert o.num_patches == meta[ident]["num_patches"], ident
+
+
+def test_map_pool_matches_the_hf_siglip_pooling_head():
+    """oracle.map_pool on tests/golden/siglip_pool.npz (transformers' SiglipVisionModel: last_hidden_state -> pooler_output),
+    through merv_amd.weights.from_hf_siglip_head -- the pooled SigLIP ids' last stage."""
+    import numpy as np
+    from oracle import merv_oracle as O
+    from merv_amd.weights import from_hf_siglip_head
+    z = np.load(Path(__file__).parent / "golden" / "siglip_pool.npz")
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")}
+    Pw = from_hf_siglip_head(sd)
+    got = O.map_pool(torch.from_numpy(z["last_hidden_state"]), Pw, heads=2, act="gelu_erf", eps=1e-6)
+    want = torch.from_numpy(z["pooler_output"])
+    assert got.shape == want.shape and torch.allclose(got, want, atol=2e-5, rtol=1e-4), float((got - want).abs().max())

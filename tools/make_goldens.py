@@ -474,3 +474,33 @@ def gen_token_selection():
 
 if __name__ == "__main__" and ("token_selection" in sys.argv[1:] or not sys.argv[1:]):
     gen_token_selection()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def gen_siglip_pool():
+    """The attention-pooling head behind the SigLIP ids that keep timm's forward() (siglip.py:46-63: every id without
+    `all-no-cls`): timm's AttentionPoolLatent is absent here, so the oracle's restatement is pinned on the same head as
+    transformers implements it (SiglipMultiheadAttentionPoolingHead: a learnt probe attends over the final-norm tokens,
+    then x + mlp(norm(x)), token 0) -- last_hidden_state in, pooler_output out, the head's state dict."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    torch.manual_seed(29)
+    cfg = SiglipVisionConfig(hidden_size=128, intermediate_size=512, num_hidden_layers=1, num_attention_heads=2,
+                             image_size=64, patch_size=16, hidden_act="gelu", layer_norm_eps=1e-6)
+    m = SiglipVisionModel(cfg).eval()
+    out = {}
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "head" in n:
+                p.add_(torch.randn_like(p) * (0.1 if p.dim() == 1 else 0.05))
+        o = m(torch.randn(3, 3, 64, 64))
+    out["last_hidden_state"] = o.last_hidden_state.numpy()   # [3, 16, 128], after post_layernorm
+    out["pooler_output"] = o.pooler_output.numpy()           # [3, 128]
+    for k, v in m.state_dict().items():
+        if "head." in k:  # `head.*` (transformers 5) or `vision_model.head.*` (4.x)
+            out["sd/" + k[k.index("head.") + 5:]] = v.numpy()
+    np.savez_compressed(OUT / "siglip_pool.npz", **out)
+    print("siglip_pool: ok", out["pooler_output"].shape, sorted(k for k in out if k.startswith("sd/")))
+
+
+if __name__ == "__main__" and ("siglip_pool" in sys.argv[1:] or not sys.argv[1:]):
+    gen_siglip_pool()
