@@ -13,6 +13,8 @@
 // exponentiated tile is already in B-operand order for O^T = V^T P^T: no LDS round trip for P.
 // V^T fragments come either from a row-major V tile read with the hardware transpose load
 // (ds_read_b64_tr_b16, VTR = true) or from a tile transposed while staging (VTR = false).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 #include "prof.h"
@@ -295,7 +297,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qx[s] = __builtin_bit_cast(bf16x8, qxraw[s]);
     }
-    for (int t = 0; t < ntiles; ++t) {
+    // One key tile. TAILK (compile time): 0 = decide at run time whether the tile is the ragged last one; 1 = a full tile;
+    // 2 = the resident kernel's last tile (sequences of 257 .. 264 tokens: 1 .. 8 keys, see tile_softmax).
+    auto tile_body = [&](const int t, auto tailk_tag) {
+        constexpr int TAILK = decltype(tailk_tag)::value;
         const int kv0 = t * 64;
         if constexpr (!RES) {
             __syncthreads();  // previous tile's LDS reads are done
@@ -311,10 +316,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         }
         const char* k_t = RES ? k_lds + kv0 * KROW : k_lds;  // this key tile's rows
         const char* v_t = RES ? v_lds + kv0 * 128 : v_lds;
-        const bool tail = kv0 + 64 > L;
+        const bool tail = TAILK == 0 ? kv0 + 64 > L : TAILK == 2;
         // 257 = 4 * 64 + 1 and 3137 = 49 * 64 + 1: in the last tile of those sequences keys 32..63 are all padding;
         // their score MFMAs, exponentials and P.V MFMAs are skipped (wave-uniform)
-        const bool both_halves = kv0 + 32 < L;
+        const bool both_halves = TAILK == 0 ? kv0 + 32 < L : TAILK == 1;
 
         // ---- S^T = K Q^T (keys on rows, queries on lanes). With <= 2 query tiles per wave all of them are issued
         //      first, so the MFMAs of tile qi+1 run in the matrix pipe under the softmax VALU work of tile qi; with 3
@@ -337,6 +342,49 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 }
             }
         };
+        // One lane's share of a score tile -> exponentials in place, returns their sum; m_new = max(m_old, tile max) * log2e-scaled.
+        // NE = 16: elements of both 32-key halves (the second only when it holds real keys), masked on the tail tile.
+        // NE = 4 (the resident kernel's tail tile: sequences of 257 .. 264 tokens leave 1 .. 8 keys there, i.e. elements 0 .. 3 of
+        // the first half in both half-waves): 4 masks / exponentials instead of 32 compares and 16 exponentials; elements 4 .. 7
+        // are zeroed for the one P.V step that still runs (keys 0 .. 15 of the tile).
+        auto tile_softmax = [&](auto ne_tag, f32x16(&sa)[2], float m_old, float& m_new) -> float {
+            constexpr int NE = decltype(ne_tag)::value;
+            constexpr int NKB = NE == 16 ? 2 : 1;
+            float mx = -INFINITY;
+            if (tail) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) {
+                        const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key >= L) sa[kb][i] = -INFINITY;  // (covers the skipped half too: its registers are stale)
+                    }
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) mx = fmaxf(mx, sa[kb][i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
+            m_new = fmaxf(m_old, mx);
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float e = fast_exp2(fmaf(sa[kb][i], sc, -m_new));
+                    sa[kb][i] = e;
+                    psum += e;
+                }
+            }
+            if constexpr (NE < 8) {
+#pragma unroll
+                for (int i = NE; i < 8; ++i) sa[0][i] = 0.f;
+            }
+            return psum;
+        };
         if constexpr (S_FIRST) {
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi]);
@@ -347,35 +395,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
             if constexpr (!S_FIRST) scores(qf[qi], sa);
             // ---- online softmax (this lane: one query, 32 of the tile's 64 keys); exponent = fma(s, c, -m c) ----
-            float mx = -INFINITY;
-            if (tail) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key >= L) sa[kb][i] = -INFINITY;  // (covers the skipped half too: its registers are stale)
-                    }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && !both_halves) continue;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[kb][i]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
-            const float m_new = fmaxf(m_run[qi], mx);
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && !both_halves) continue;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = fast_exp2(fmaf(sa[kb][i], sc, -m_new));
-                    sa[kb][i] = e;
-                    psum += e;
-                }
-            }
+            float m_new;
+            const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sa, m_run[qi], m_new);
             if (!__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
                 const float alpha = fast_exp2(m_run[qi] - m_new);
                 l_run[qi] *= alpha;
@@ -406,34 +427,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
                 f32x16 sx[2];
                 scores(qx, sx);
-                if (tail) {
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                            if (key >= L) sx[kb][i] = -INFINITY;
-                        }
-                }
-                float mx = -INFINITY;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (kb == 1 && !both_halves) continue;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sx[kb][i]);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // finite: key kv0 of every tile is a real key
-                float psum = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    if (kb == 1 && !both_halves) continue;
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float e = fast_exp2(fmaf(sx[kb][i], sc, -mx));
-                        sx[kb][i] = e;
-                        psum += e;
-                    }
-                }
+                float mx;  // the tile's own maximum (finite: key kv0 of every tile is a real key); partials are merged after the loop
+                const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sx, -INFINITY, mx);
                 f32x16 ox[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { ox[0][i] = 0.f; ox[1][i] = 0.f; }
@@ -463,6 +458,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             }
         }
         MERV_STAMP(5 + 4 * t);
+    };
+    if constexpr (RES) {  // L in (256, 264]: four full tiles, then the 1 .. 8 keys of the fifth
+        for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{});
+        tile_body(ntiles - 1, std::integral_constant<int, 2>{});
+    } else {
+        for (int t = 0; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{});
     }
     MERV_STAMP(30);
 
