@@ -60,3 +60,25 @@ ends = {e: n for s, e, n in ev}
 starts = {s: n for s, e, n in ev}
 for g, a, b in sorted(gaps, reverse=True)[:8]:
     print("  gap %.1f us after %s before %s" % (g / 1e3, ends.get(a, "?")[30:80], starts.get(b, "?")[30:80]))
+
+# ---- per class: how long its kernels are the ONLY thing running (a launch on a few CUs then idles the rest of the chip)
+def klass(n):
+    return ("gemm 8-phase" if "8phase" in n else "gemm other" if "gemm_bf16" in n else "attention" if "attn_kernel" in n and "temporal" not in n
+            else "temporal attn" if "temporal" in n else "layernorm/stats" if ("layernorm" in n or "stats" in n) else "other")
+pts2 = []
+for i, (s, e, n) in enumerate(ev):
+    pts2.append((s, 1, i)); pts2.append((e, -1, i))
+pts2.sort()
+running, last = set(), t0
+alone = collections.Counter()
+for t, d, i in pts2:
+    if len(running) == 1:
+        alone[klass(ev[next(iter(running))][2])] += t - last
+    last = t
+    if d == 1:
+        running.add(i)
+    else:
+        running.discard(i)
+print("time a class runs ALONE on the chip:", {k: "%.2f ms (%.1f %% of the span)" % (v / 1e6, 100.0 * v / span) for k, v in alone.most_common()})
+small = [(e - s) for s, e, n in ev if klass(n) == "gemm other"]
+print("gemm other: %d launches, mean %.1f us" % (len(small), sum(small) / len(small) / 1e3))
