@@ -323,6 +323,10 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
 /* three projections of the same input in one launch (q_proj / k_proj / v_proj): y_i[N_i] = bf16(W_i[N_i,K] x[K]) */
 int merv_decode_gemv3(const void *Wa, const void *Wb, const void *Wc, const void *x, void *ya, void *yb, void *yc,
                       int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void *norm_w, float norm_eps, void *stream);
+/* the same with nn.Linear biases (bf16 [N_i] or NULL each): Qwen2's q / k / v projections */
+int merv_decode_gemv3_bias(const void *Wa, const void *Wb, const void *Wc, const void *x, void *ya, void *yb, void *yc,
+                           int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void *norm_w, float norm_eps,
+                           const void *bias_a, const void *bias_b, const void *bias_c, void *stream);
 size_t merv_decode_attention_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention(const void *q, const void *k_cache, const void *v_cache, void *out, float *ws, const int64_t *pos,
                           int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, int32_t nsplit, float scale, void *stream);

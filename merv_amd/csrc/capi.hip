@@ -795,6 +795,12 @@ extern "C" int merv_decode_gemv(const void* W, const void* W2, const void* x, co
 
 extern "C" int merv_decode_gemv3(const void* Wa, const void* Wb, const void* Wc, const void* x, void* ya, void* yb, void* yc,
                                  int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void* norm_w, float norm_eps, void* stream_) {
+    return merv_decode_gemv3_bias(Wa, Wb, Wc, x, ya, yb, yc, Na, Nb, Nc, K, norm_w, norm_eps, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int merv_decode_gemv3_bias(const void* Wa, const void* Wb, const void* Wc, const void* x, void* ya, void* yb, void* yc,
+                                      int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void* norm_w, float norm_eps,
+                                      const void* bias_a, const void* bias_b, const void* bias_c, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(Wa && Wb && Wc && x && ya && yb && yc, "merv_decode_gemv3: null argument");
     MERV_CHECK(Na > 0 && Nb > 0 && Nc > 0 && Na % 2 == 0 && Nb % 2 == 0 && Nc % 2 == 0 && K > 0 && K % 8 == 0,
@@ -803,6 +809,7 @@ extern "C" int merv_decode_gemv3(const void* Wa, const void* Wb, const void* Wc,
     a.W = (const bf16_t*)Wa; a.Wb = (const bf16_t*)Wb; a.Wc = (const bf16_t*)Wc; a.x = (const bf16_t*)x;
     a.y = (bf16_t*)ya; a.yb = (bf16_t*)yb; a.yc = (bf16_t*)yc; a.N = Na; a.Nb = Nb; a.Nc = Nc; a.K = K;
     a.norm_w = (const bf16_t*)norm_w; a.norm_eps = norm_eps;
+    a.bias = (const bf16_t*)bias_a; a.bias_b = (const bf16_t*)bias_b; a.bias_c = (const bf16_t*)bias_c;
     MERV_HIP(launch_decode_gemv(a, (hipStream_t)stream_));
     return 0;
 }

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     if constexpr (NW_MATS == 1) {
         if (n0 >= p.N && p.Nb > 0) {
             n0 -= p.N;
-            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; }
-            else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; }
+            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }
+            else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; p.bias = p.bias_c; }
         }
     }
     if (n0 >= p.N) return;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
         for (int r = 0; r < GEMV_ROWS; ++r) {
             const int n = n0 + r;
             if (n >= p.N) break;
-            float v = round_bf(acc[0][r]);  // the nn.Linear output as a bf16 tensor
+            float v = round_bf(NW_MATS == 1 && p.bias ? acc[0][r] + bf2f(p.bias[n]) : acc[0][r]);  // the nn.Linear output as a bf16 tensor
             if constexpr (NW_MATS == 2) {
                 const float g = v;
                 const float s = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor

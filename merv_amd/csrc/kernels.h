@@ -298,6 +298,11 @@ struct DecodeGemvArgs {  // y = bf16(W x) (+ res), or with W2: y = silu(bf16(W x
     // same two roundings as the stand-alone kernel, so the result is bit-identical to rmsnorm + gemv
     const bf16_t* norm_w;  // [K] or nullptr
     float norm_eps;
+    // nn.Linear biases of the (up to three) matrices, bf16 [N] / [Nb] / [Nc] or nullptr (Qwen2's q / k / v projections):
+    // added to the fp32 accumulator before the one rounding of the output
+    const bf16_t* bias;
+    const bf16_t* bias_b;
+    const bf16_t* bias_c;
 };
 hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s);
 

@@ -34,9 +34,40 @@ def mistral_7b_config() -> Dict:
                 bos_token_id=1, eos_token_id=2, pad_token_id=32000)
 
 
+def llama3_8b_config() -> Dict:
+    """meta-llama/Meta-Llama-3-8B geometry (GQA 32/8, 128 256 tokens + the reference's <PAD>, resized to a multiple of 64:
+    llama3.py:46-48)."""
+    return dict(vocab_size=128320, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32, num_attention_heads=32,
+                num_key_value_heads=8, max_position_embeddings=8192, rms_norm_eps=1e-5, rope_theta=500000.0, bos_token_id=128000,
+                eos_token_id=128001, pad_token_id=128256)
+
+
+def llama31_8b_config() -> Dict:
+    """meta-llama/Meta-Llama-3.1-8B-Instruct: the same tower with the "llama3" frequency-dependent rotary scaling and the
+    tokenizer's own <|finetune_right_pad_id|> = 128004 as pad (llama3.py:101-102: no resize)."""
+    return dict(llama3_8b_config(), vocab_size=128256, max_position_embeddings=131072, pad_token_id=128004,
+                rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                              "original_max_position_embeddings": 8192})
+
+
+def qwen25_7b_config() -> Dict:
+    """Qwen/Qwen2.5-7B-Instruct geometry (GQA 28/4, q / k / v biases)."""
+    return dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
+                num_key_value_heads=4, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=False,
+                bos_token_id=151643, eos_token_id=151645, use_sliding_window=False)
+
+
+def qwen25_3b_config() -> Dict:
+    """Qwen/Qwen2.5-3B-Instruct geometry (GQA 16/2, tied embeddings)."""
+    return dict(vocab_size=151936, hidden_size=2048, intermediate_size=11008, num_hidden_layers=36, num_attention_heads=16,
+                num_key_value_heads=2, max_position_embeddings=32768, rms_norm_eps=1e-6, rope_theta=1e6, tie_word_embeddings=True,
+                bos_token_id=151643, eos_token_id=151645, use_sliding_window=False)
+
+
 class LlamaBackbone:
-    """`family`: "llama" (LlamaForCausalLM) or "mistral" (MistralForCausalLM); `identifier` is the reference's LLM
-    registry key (materialize.py:76-101) and picks the prompt builder (llama2.py:78-89)."""
+    """`family`: "llama" (LlamaForCausalLM: Llama-2 / Vicuna / Llama-3 / 3.1), "mistral" (MistralForCausalLM) or "qwen2"
+    (Qwen2ForCausalLM); `identifier` is the reference's LLM registry key (materialize.py:76-101) and picks the prompt builder
+    (llama2.py:78-89, llama3.py:50-56,104-105, qwen2.py:51-53)."""
 
     def __init__(self, config: Optional[Dict] = None, device="cuda:0", dtype=torch.bfloat16, seed: int = 0,
                  state_dict: Optional[Dict] = None, llm_max_length: int = 2048, family: str = "llama",
@@ -45,6 +76,8 @@ class LlamaBackbone:
             from transformers import LlamaConfig as Cfg, LlamaForCausalLM as Cls
         elif family == "mistral":
             from transformers import MistralConfig as Cfg, MistralForCausalLM as Cls
+        elif family == "qwen2":
+            from transformers import Qwen2Config as Cfg, Qwen2ForCausalLM as Cls
         else:
             raise ValueError(f"unknown LLM family `{family}`")
         cfg = Cfg(**(config or llama2_7b_config()))
@@ -71,12 +104,17 @@ class LlamaBackbone:
 
     @property
     def prompt_builder_fn(self):
-        from .prompting import LLaMa2ChatPromptBuilder, MistralInstructPromptBuilder, PurePromptBuilder, VicunaV15ChatPromptBuilder
+        from .prompting import (LLaMa2ChatPromptBuilder, LLaMa31PromptBuilder, MistralInstructPromptBuilder, PurePromptBuilder,
+                                Qwen2PromptBuilder, VicunaV15ChatPromptBuilder)
         i = self.identifier
+        if i.startswith("llama3.1-"):
+            return LLaMa31PromptBuilder  # llama3.py:104-105
+        if i.startswith("qwen2"):
+            return Qwen2PromptBuilder  # qwen2.py:51-53
         if i.endswith("-pure"):
             return PurePromptBuilder
-        if i.startswith("llama2-") and i.endswith("-chat"):
-            return LLaMa2ChatPromptBuilder
+        if (i.startswith("llama2-") or i.startswith("llama3-")) and i.endswith("-chat"):
+            return LLaMa2ChatPromptBuilder  # llama3.py:54-55 keeps the Llama-2 chat wrapper for llama3-*-chat
         if i.startswith("vicuna"):
             return VicunaV15ChatPromptBuilder
         if i.startswith("mistral") and i.endswith("-instruct"):
@@ -178,14 +216,21 @@ class StaticDecoder:
         self.max_len, self.B = max_len, batch
         p = next(hf_model.parameters())
         self.dev, self.dt = p.device, p.dtype
-        theta = getattr(cfg, "rope_theta", None)
-        if theta is None and isinstance(getattr(cfg, "rope_parameters", None), dict):
-            theta = cfg.rope_parameters.get("rope_theta")
-        theta = float(theta or 10000.0)
-        inv = 1.0 / (theta ** (torch.arange(0, self.hd, 2, dtype=torch.float32, device=self.dev) / self.hd))
-        fr = torch.outer(torch.arange(max_len, dtype=torch.float32, device=self.dev), inv)
-        emb = torch.cat([fr, fr], dim=-1)
-        self.cos, self.sin = emb.cos().to(self.dt), emb.sin().to(self.dt)  # [max_len, hd]
+        rot = getattr(getattr(hf_model, "model", None), "rotary_emb", None)
+        if rot is not None:
+            # the module's own rotary embedding: plain RoPE (Llama-2, Mistral, Qwen2), Llama-3.1's frequency-dependent scaling, ...
+            with torch.no_grad():
+                cos, sin = rot(torch.zeros(1, dtype=self.dt, device=self.dev), torch.arange(max_len, device=self.dev)[None])
+            self.cos, self.sin = cos[0].to(self.dt).contiguous(), sin[0].to(self.dt).contiguous()  # [max_len, hd]
+        else:
+            theta = getattr(cfg, "rope_theta", None)
+            if theta is None and isinstance(getattr(cfg, "rope_parameters", None), dict):
+                theta = cfg.rope_parameters.get("rope_theta")
+            theta = float(theta or 10000.0)
+            inv = 1.0 / (theta ** (torch.arange(0, self.hd, 2, dtype=torch.float32, device=self.dev) / self.hd))
+            fr = torch.outer(torch.arange(max_len, dtype=torch.float32, device=self.dev), inv)
+            emb = torch.cat([fr, fr], dim=-1)
+            self.cos, self.sin = emb.cos().to(self.dt), emb.sin().to(self.dt)  # [max_len, hd]
         L = cfg.num_hidden_layers
         self.K = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
         self.V = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
@@ -289,8 +334,8 @@ class HipDecoder(StaticDecoder):
         hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
         p = next(hf_model.parameters())
         lyr = hf_model.model.layers[0]
-        return (batch == 1 and hd == 128 and p.is_cuda and p.dtype == torch.bfloat16 and lyr.self_attn.q_proj.bias is None
-                and lyr.self_attn.o_proj.bias is None and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0)
+        return (batch == 1 and hd == 128 and p.is_cuda and p.dtype == torch.bfloat16 and lyr.self_attn.o_proj.bias is None
+                and getattr(lyr.mlp.gate_proj, "bias", None) is None and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0)
 
     def __init__(self, hf_model, max_len: int, batch: int = 1) -> None:
         super().__init__(hf_model, max_len, batch)
@@ -321,9 +366,11 @@ class HipDecoder(StaticDecoder):
             for li, lyr in enumerate(m.model.layers):
                 a, mlp = lyr.self_attn, lyr.mlp
                 # input_layernorm fused into the q / k / v launch, post_attention_layernorm into the gate / up launch
-                check(lib.merv_decode_gemv3(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), x, ptr(self.q), ptr(self.k),
-                                            ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps, st),
-                      "merv_decode_gemv3")
+                bq, bk, bv = a.q_proj.bias, a.k_proj.bias, a.v_proj.bias  # Qwen2 has them, Llama / Mistral do not
+                check(lib.merv_decode_gemv3_bias(ptr(a.q_proj.weight), ptr(a.k_proj.weight), ptr(a.v_proj.weight), x, ptr(self.q), ptr(self.k),
+                                                 ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps,
+                                                 0 if bq is None else ptr(bq), 0 if bk is None else ptr(bk), 0 if bv is None else ptr(bv), st),
+                      "merv_decode_gemv3_bias")
                 check(lib.merv_decode_attention_fused(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
                                                       ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT,
                                                       hd**-0.5, st), "merv_decode_attention_fused")
@@ -341,6 +388,10 @@ LLM_BACKBONES = {
     "vicuna-v15-7b": ("llama", llama2_7b_config), "vicuna-v15-13b": ("llama", llama2_13b_config),
     # BASELINE.json configs[4]: the Mistral-7B-Instruct swap, a new backbone modelled on llama2.py:55-98
     "mistral-v0.2-7b-pure": ("mistral", mistral_7b_config), "mistral-v0.2-7b-instruct": ("mistral", mistral_7b_config),
+    # the reference's remaining registry keys (materialize.py:90-100)
+    "llama3-8b-pure": ("llama", llama3_8b_config), "llama3-8b-chat": ("llama", llama3_8b_config),
+    "llama3.1-8b-chat": ("llama", llama31_8b_config),
+    "qwen2.5-7b-instruct": ("qwen2", qwen25_7b_config), "qwen2.5-3b-instruct": ("qwen2", qwen25_3b_config),
 }
 
 

@@ -108,3 +108,43 @@ class MistralInstructPromptBuilder(PromptBuilder):
 
     def _first(self, message: str) -> str:
         return self._human(self.system_prompt + message)
+
+
+class _HeaderChatPromptBuilder(PromptBuilder):
+    """The chat-template builders (llama2_chat_prompter.py:91-123, qwen2_prompter.py:11-42): the system block opens the prompt,
+    a human turn is wrapped together with the assistant header that follows it, and -- unlike the older builders -- messages
+    are taken verbatim (no `<image>` removal, no stripping) and get_prompt() returns the text as is. No system-prompt argument."""
+
+    SYSTEM = HUMAN = GPT_END = ""
+
+    def __init__(self, model_family: str, system_prompt: Optional[str] = None) -> None:
+        if system_prompt is not None:
+            raise TypeError(f"{type(self).__name__} takes no system_prompt (the reference's class has no such argument)")
+        super().__init__(model_family, SYS_PROMPTS[model_family])
+        self.prompt = self.SYSTEM.format(self.system_prompt)
+
+    def add_turn(self, role: str, message: str) -> str:
+        expected = "gpt" if self.turn_count % 2 else "human"
+        assert role == expected, f"turn {self.turn_count} must come from `{expected}`, got `{role}`"
+        wrapped = self.HUMAN.format(message) if role == "human" else message + self.GPT_END
+        self.prompt += wrapped
+        self.turn_count += 1
+        return wrapped
+
+    def get_potential_prompt(self, message: str):
+        return None  # the reference's method only evaluates an assert on an exception instance and returns None
+
+    def get_prompt(self) -> str:
+        return self.prompt
+
+
+class LLaMa31PromptBuilder(_HeaderChatPromptBuilder):
+    SYSTEM = "<|start_header_id|>system<|end_header_id|>\n\n{}<|eot_id|>"  # <|begin_of_text|> comes from the tokenizer
+    HUMAN = "<|start_header_id|>user<|end_header_id|>\n\n{}<|eot_id|><|start_header_id|>assistant<|end_header_id|>\n\n"
+    GPT_END = "<|eot_id|>"
+
+
+class Qwen2PromptBuilder(_HeaderChatPromptBuilder):
+    SYSTEM = "<|im_start|>system\n{}<|im_end|>\n"
+    HUMAN = "<|im_start|>user\n{}<|im_end|>\n<|im_start|>assistant\n"
+    GPT_END = "<|im_end|>"

@@ -178,7 +178,7 @@ def test_fused_attention_launch_equals_the_three_kernels(dev, H, Hkv, pos):
     assert rel_l2(out_c, ref) < 6e-3 and rel_l2(out_c, out_a) < 6e-3
 
 
-@pytest.mark.parametrize("kv_heads,family", [(2, "llama"), (1, "mistral")])
+@pytest.mark.parametrize("kv_heads,family", [(2, "llama"), (1, "mistral"), (1, "llama3.1"), (1, "qwen2")])
 def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
     """Same random model, same prefill (PyTorch-ROCm, as the north_star keeps it), then token-by-token decode on both decoders,
     both fed the PyTorch decoder's greedy tokens: logits within the bf16 tolerance at every step, graph replay == eager."""
@@ -187,7 +187,18 @@ def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
                num_key_value_heads=kv_heads, max_position_embeddings=2048, bos_token_id=1, eos_token_id=2, pad_token_id=0)
     if family == "mistral":
         cfg.update(rope_theta=1e6, sliding_window=None)
+    if family == "llama3.1":  # GQA + the "llama3" frequency-dependent rotary scaling (tables from the module's rotary embedding)
+        cfg.update(rope_theta=500000.0, rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                                      "high_freq_factor": 4.0, "original_max_position_embeddings": 64})
+        family = "llama"
+    if family == "qwen2":  # q / k / v biases (merv_decode_gemv3_bias), tied embeddings
+        cfg.update(rope_theta=1e6, tie_word_embeddings=True, use_sliding_window=False)
     llm = LlamaBackbone(cfg, device=dev, family=family)
+    if family == "qwen2":
+        with torch.no_grad():
+            for lyr in llm.llm.model.layers:  # HF initialises the biases to zero: make them matter
+                for pr in (lyr.self_attn.q_proj, lyr.self_attn.k_proj, lyr.self_attn.v_proj):
+                    pr.bias.normal_(0, 0.5)
     assert HipDecoder.supports(llm.llm, 1) and not HipDecoder.supports(llm.llm, 2)
     ref, hip, hip_eager = StaticDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1)
     emb = (torch.randn(1, 37, 256, generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16).to(dev)

@@ -186,6 +186,19 @@ def test_chat_prompt_builders_match_reference_strings():
             assert pb.get_potential_prompt("And then?") == c["potential"]
 
 
+def test_header_style_prompt_builders_match_reference_strings():
+    import merv_amd.prompting as P
+    cases = json.loads((G / "prompts_header.json").read_text())  # reference LLaMa31PromptBuilder / Qwen2PromptBuilder
+    assert {c["builder"] for c in cases} == {"LLaMa31PromptBuilder", "Qwen2PromptBuilder"}
+    for c in cases:
+        pb = getattr(P, c["builder"])("merv")
+        for t in c["turns"]:
+            assert pb.add_turn(t["role"], t["message"]) == t["wrapped"]
+        assert pb.get_prompt() == c["prompt"]
+    with pytest.raises(TypeError):
+        P.Qwen2PromptBuilder("merv", system_prompt="x")
+
+
 def test_load_video_predecoded_and_gif(tmp_path):
     import numpy as np
     from PIL import Image
@@ -235,7 +248,16 @@ def test_llm_registry_families_and_prompt_builders():
     tiny = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
                 num_key_value_heads=2, max_position_embeddings=128, bos_token_id=1, eos_token_id=2, pad_token_id=0)
     names = {"llama2-7b-pure": "PurePromptBuilder", "llama2-13b-chat": "LLaMa2ChatPromptBuilder",
-             "vicuna-v15-7b": "VicunaV15ChatPromptBuilder", "mistral-v0.2-7b-instruct": "MistralInstructPromptBuilder"}
+             "vicuna-v15-7b": "VicunaV15ChatPromptBuilder", "llama3-8b-pure": "PurePromptBuilder",
+             "llama3-8b-chat": "LLaMa2ChatPromptBuilder",  # llama3.py:54-55 keeps the Llama-2 chat wrapper
+             "llama3.1-8b-chat": "LLaMa31PromptBuilder", "qwen2.5-7b-instruct": "Qwen2PromptBuilder",
+             "qwen2.5-3b-instruct": "Qwen2PromptBuilder", "mistral-v0.2-7b-instruct": "MistralInstructPromptBuilder"}
+    # every key of the reference's LLM registry (materialize.py:76-101) is present
+    for k in ("llama2-7b-pure", "llama2-13b-pure", "llama2-7b-chat", "llama2-13b-chat", "vicuna-v15-7b", "vicuna-v15-13b",
+              "llama3-8b-pure", "llama3-8b-chat", "llama3.1-8b-chat", "qwen2.5-7b-instruct", "qwen2.5-3b-instruct"):
+        assert k in LLM_BACKBONES
+    assert LLM_BACKBONES["llama3.1-8b-chat"][1]()["rope_scaling"]["rope_type"] == "llama3"
+    assert LLM_BACKBONES["qwen2.5-3b-instruct"][1]()["tie_word_embeddings"] is True
     for llm_id, builder in names.items():
         assert llm_id in LLM_BACKBONES
         llm, tok = get_llm_backbone_and_tokenizer(llm_id, config=dict(tiny), device="cpu")
@@ -301,11 +323,19 @@ def test_static_decoder_matches_hf_forward_cpu():
     """StaticDecoder (torch-native prefill + static-cache decode, the body of the hipGraph-replayed decode step) against
     the HF module's own forward with its dynamic cache, fp32, Llama (MHA) and Mistral (GQA)."""
     from merv_amd.llm import LlamaBackbone, StaticDecoder
-    for fam, kv in (("llama", 4), ("mistral", 2)):
+    for fam, kv in (("llama", 4), ("mistral", 2), ("llama3.1", 2), ("qwen2", 2), ("qwen2-tied", 1)):
         cfg = dict(vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
                    num_key_value_heads=kv, max_position_embeddings=64, rms_norm_eps=1e-5, bos_token_id=1, eos_token_id=2, pad_token_id=0)
         if fam == "mistral":
             cfg["sliding_window"] = None
+        if fam == "llama3.1":  # frequency-dependent rotary scaling: the tables come from the module's own rotary embedding
+            cfg.update(rope_theta=500000.0, max_position_embeddings=256,
+                       rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                                     "original_max_position_embeddings": 16})
+            fam = "llama"
+        if fam.startswith("qwen2"):  # q / k / v biases; the 3B model ties lm_head to the embedding
+            cfg.update(rope_theta=1e6, tie_word_embeddings=fam.endswith("tied"), use_sliding_window=False)
+            fam = "qwen2"
         bb = LlamaBackbone(cfg, device="cpu", dtype=torch.float32, family=fam)
         emb = torch.randn(2, 9, 64, generator=torch.Generator().manual_seed(1))
         dec = StaticDecoder(bb.llm, 16, 2)

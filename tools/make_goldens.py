@@ -326,6 +326,20 @@ def gen_prompts():
                                    "potential": pb.get_potential_prompt("And then?") if len(turns) % 2 == 0 else None})
     (OUT / "prompts_chat.json").write_text(json.dumps(chat_cases, indent=1))
     print("prompts_chat: ok", len(chat_cases))
+    # the header-style builders (Llama-3.1 in llama2_chat_prompter.py, Qwen2): no system-prompt argument, no stripping
+    hdr_cases = []
+    l2 = sys.modules["ref_prompting.llama2_chat_prompter"]
+    q2 = _load("ref_prompting.qwen2_prompter", base / "qwen2_prompter.py", package="ref_prompting")
+    for mod, cls in ((l2, "LLaMa31PromptBuilder"), (q2, "Qwen2PromptBuilder")):
+        for turns in (["<image>\nWhat is happening in this video?"], ["Describe the video. ", "A cat jumps.", "What colour is it?"], ["Q1", "", "Q2", "A2"]):
+            pb = getattr(mod, cls)("merv")
+            seq = []
+            for i, msg in enumerate(turns):
+                role = "human" if i % 2 == 0 else "gpt"
+                seq.append({"role": role, "message": msg, "wrapped": pb.add_turn(role, msg)})
+            hdr_cases.append({"builder": cls, "turns": seq, "prompt": pb.get_prompt()})
+    (OUT / "prompts_header.json").write_text(json.dumps(hdr_cases, indent=1))
+    print("prompts_header: ok", len(hdr_cases))
 
 
 if __name__ == "__main__":
