@@ -187,7 +187,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="videos per GPU per step")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="videos per GPU per step (16 since round 2: +1.6 %% tokens/s over 8, +2.3 %% at 24 -- less tile quantisation per GEMM "
+                         "launch; rounds 1 / 2 A/B numbers in DESIGN.md are quoted at 8)")
     ap.add_argument("--sequential", action="store_true", help="run the encoders on one stream (reference behaviour)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "units"],
                     help="what `value` measures at N > 1: 'dp' = every rank runs the whole path on its own videos (independent "
@@ -364,12 +366,14 @@ def main():
             achieved = fl.value / (ms.value * 1e-3) / 1e12
             traffic = traffic_source = None
             tf = ROOT / PMC_TRAFFIC_FILE
-            if tf.exists() and not args.mxfp8 and B == 8:
+            if tf.exists() and not args.mxfp8:
                 try:
-                    per_step = json.loads(tf.read_text()).get("hbm_bytes_per_step")
+                    doc = json.loads(tf.read_text())
+                    per_step = doc.get("hbm_bytes_per_step") if doc.get("videos_per_step", 8) == B else None
                     traffic = per_step / (n.value / args.steps) if per_step else None  # per GEMM call, like `achieved`
-                    traffic_source = (f"{PMC_TRAFFIC_FILE}: FETCH_SIZE x2 + WRITE_SIZE from the builder's separate rocprofv3 --pmc passes of "
-                                      "this command (committed file, NOT measured in this run)")
+                    if traffic is not None:
+                        traffic_source = (f"{PMC_TRAFFIC_FILE}: FETCH_SIZE x2 + WRITE_SIZE from the builder's separate rocprofv3 --pmc passes "
+                                          "of this command (committed file, NOT measured in this run)")
                 except Exception:
                     traffic = None
             roof = {"bound": "mfma",
