@@ -458,3 +458,12 @@ int main() {
     assert out.returncode == 0, out.stderr[-2000:]
     got = [[int(x) for x in line.split()] for line in out.stdout.strip().split("\n")]
     assert got == [c["ids"] for c in cases]
+
+
+def test_temporal_subsample_matches_the_reference_generate_body():
+    """merv_temporal_subsample (host-only C ABI) against the frame selections the reference's own MERV.generate body produced
+    (merv.py:796-806; tests/golden/merv_forward.json, tools/make_goldens.py gen_merv_forward)."""
+    from merv_amd.sampler import temporal_subsample
+    for c in json.loads((G / "merv_forward.json").read_text())["generate_subsample"]:
+        for nf, sel in zip(c["num_frames"], c["selected"]):
+            assert temporal_subsample(c["frames_loaded"], max(c["num_frames"]), nf) == sel, c

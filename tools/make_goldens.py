@@ -109,11 +109,22 @@ def gen_frame_indices():
 
 
 # ----------------------------------------------------------------------------------------------------------
+def _stub_module(name, is_pkg=False):
+    """An empty stand-in module WITH a __spec__: transformers probes optional packages through importlib.util.find_spec,
+    which raises ValueError on a sys.modules entry whose __spec__ is None (the no-argument run used to die there)."""
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, loader=None, is_package=is_pkg)
+    if is_pkg:
+        m.__path__ = []
+    return m
+
+
 def _stub_timm():
-    timm = types.ModuleType("timm")
-    layers = types.ModuleType("timm.layers")
-    models = types.ModuleType("timm.models")
-    regnet = types.ModuleType("timm.models.regnet")
+    timm = _stub_module("timm", True)
+    layers = _stub_module("timm.layers")
+    models = _stub_module("timm.models", True)
+    regnet = _stub_module("timm.models.regnet")
     layers.LayerNorm2d = torch.nn.LayerNorm
     layers.trunc_normal_ = torch.nn.init.trunc_normal_
     regnet.RegStage = object
@@ -179,7 +190,7 @@ def _load_languagebind():
     import transformers.models.clip.modeling_clip as mc
     if not hasattr(mc, "clip_loss"):
         mc.clip_loss = lambda similarity: similarity.mean()  # never called on the vision path
-    peft = types.ModuleType("peft")
+    peft = _stub_module("peft")
     peft.LoraConfig = object
     peft.get_peft_model = lambda m, c: m
     sys.modules["peft"] = peft
@@ -342,21 +353,6 @@ def gen_prompts():
     print("prompts_header: ok", len(hdr_cases))
 
 
-if __name__ == "__main__":
-    which = sys.argv[1:] or ["frames", "projfus", "lb", "vivit", "hf", "prompts", "preprocess"]
-    torch.set_num_threads(8)
-    if "frames" in which:
-        gen_frame_indices()
-    if "projfus" in which:
-        gen_projector_fusion()
-    if "lb" in which:
-        gen_languagebind()
-    if "vivit" in which:
-        gen_vivit()
-    if "hf" in which:
-        gen_hf_crosscheck()
-    if "prompts" in which:
-        gen_prompts()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -409,8 +405,6 @@ def gen_preprocess():
     print("preprocess: ok", len(out), "arrays")
 
 
-if __name__ == "__main__" and ("preprocess" in sys.argv[1:] or not sys.argv[1:]):
-    gen_preprocess()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -486,8 +480,6 @@ def gen_token_selection():
     print("token_selection:", {k: tuple(v.shape) for k, v in out.items() if "hidden" not in k and "pooled" not in k})
 
 
-if __name__ == "__main__" and ("token_selection" in sys.argv[1:] or not sys.argv[1:]):
-    gen_token_selection()
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -516,5 +508,197 @@ def gen_siglip_pool():
     print("siglip_pool: ok", out["pooler_output"].shape, sorted(k for k in out if k.startswith("sd/")))
 
 
-if __name__ == "__main__" and ("siglip_pool" in sys.argv[1:] or not sys.argv[1:]):
-    gen_siglip_pool()
+
+
+# ----------------------------------------------------------------------------------------------------------
+def _ref_class(path: Path, cls: str, names, base, extra_globals=None):
+    """A class object holding the reference's own method bodies `names` of `cls` (compiled from that file's AST nodes,
+    decorators kept) on top of the stand-in base class `base`, so `self.<collaborator>` and a zero-argument `super()`
+    resolve to stand-ins. The module cannot be imported here (draccus / timm / torchvision); the bodies need only torch.
+    Compiled with `from __future__ import annotations` in force, as the reference file declares (merv.py:14)."""
+    import __future__
+    import ast
+    tree = ast.parse(path.read_text())
+    node = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    fns = [n for n in node.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(fns) == len(names), (names, [f.name for f in fns])
+    klass = ast.ClassDef(name=cls, bases=[ast.Name(id="_StandInBase", ctx=ast.Load())], keywords=[], body=fns, decorator_list=[])
+    if sys.version_info >= (3, 12):
+        klass.type_params = []
+    ns = {"torch": torch, "np": np, "_StandInBase": base}
+    ns.update(extra_globals or {})
+    code = compile(ast.fix_missing_locations(ast.Module(body=[klass], type_ignores=[])), str(path), "exec",
+                   flags=__future__.annotations.compiler_flag)
+    exec(code, ns)
+    return ns[cls], ns  # ns is the methods' globals: stand-ins for module-level names (load_video, ...) go there
+
+
+def gen_merv_forward():
+    """The reference's own `MERV.forward` body (merv/models/vidlms/merv.py:503-734) and the frame sub-sampling of
+    `MERV.generate` (:778-830, the `video[:: max(num_frames) // num_frame]` of :803-806) executed here on a stand-in `self`:
+    video backbones are callables returning given tokens (with temporal_resolution / spatial_resolution), projectors and
+    fusion are the reference's real nn_utils classes, `llm_backbone` records what it is called with. Pins the oracle's
+    visual_path tail (reshape -> projectors -> fusion), splice and assemble_training_batch, and the product's
+    merv_splice_forward / train.assemble_training_batch / sampler.temporal_subsample."""
+    from typing import List, Optional
+    _stub_timm()
+    nn_utils = _load("ref_nn_utils", REF / "merv/util/nn_utils.py")
+    NS = types.SimpleNamespace
+    out, meta = {}, {}
+
+    class Recorder:
+        def __init__(self, table, bos_token):
+            self.table, self.tokenizer, self.calls = table, NS(bos_token=bos_token, pad_token_id=0), []
+            self.half_precision_dtype = torch.bfloat16
+
+        def embed_input_ids(self, ids):
+            return self.table[ids]
+
+        def __call__(self, **kw):
+            self.calls.append(kw)
+            return kw
+
+    class Base:
+        def generate(self, **kw):  # GenerationMixin.generate stand-in (merv.py:818)
+            self.generate_kwargs = kw
+            return torch.zeros(1, kw["input_ids"].shape[1] + 3, dtype=torch.long)
+
+    MERV, ref_globals = _ref_class(REF / "merv/models/vidlms/merv.py", "MERV", ["forward", "generate"], Base,
+                                   {"IGNORE_INDEX": -100, "Optional": Optional, "List": List, "CausalLMOutputWithPast": dict,
+                                    "Image": None, "load_video": None})
+
+    # ---- forward: merv-full's structure at reduced widths: 4 encoders, T = 2 frames, spatial 16^2 / 16^2 / 14^2 / 14^2 -> 8^2,
+    #      so 128 visual tokens of width llm = 128 (widths the HIP GEMM accepts: K % 64 == 0, N % 128 == 0, so the SAME fixture
+    #      drives the -m gpu test; encoder tokens fp16-representable: stored as fp16)
+    g = torch.Generator().manual_seed(2024)
+    T, llm, Cs, Ss = 2, 128, (64, 64, 64, 64), (256, 256, 196, 196)
+    torch.manual_seed(1024)  # merv.py:87
+    projectors = [nn_utils.AveragePooling3DProjector(C, llm, output_frames=T, output_size=8, mlp_type="linear").eval() for C in Cs]
+    fusion = nn_utils.CrossAttentionAdapterLearnableQuery(embed_dim=48, llm_dim=llm, token_length=T * 64, averagetoken=True).eval()
+    with torch.no_grad():
+        fusion.attention.in_proj_bias.normal_(0, 0.1, generator=g)
+        fusion.Q.mul_(8.0)
+    for i, p in enumerate(projectors):
+        out[f"proj{i}_w"] = p.state_dict()["projector.projector.weight"].numpy()
+        out[f"proj{i}_b"] = p.state_dict()["projector.projector.bias"].numpy()
+    for k in ("Q", "attention.q_proj_weight", "attention.k_proj_weight", "attention.in_proj_bias"):
+        out[f"fus_{k}"] = fusion.state_dict()[k].numpy()
+    vocab = 50
+    table = torch.randn(vocab, llm, generator=g)
+    out["embed_table"] = table.numpy()
+
+    def run(tag, B, S, multimodal_indices, bos_token, with_masks=True):
+        feats = [torch.randn(B, T * s, C, generator=g).half().float() for s, C in zip(Ss, Cs)]
+        fused_rec = {}
+
+        def fusion_rec(xs):
+            y, w = fusion(xs)
+            fused_rec["y"], fused_rec["w"] = y, w
+            return y, w
+
+        me = MERV.__new__(MERV)
+        me.llm_backbone = Recorder(table, bos_token)
+        me.video_backbone_requires_grad = False
+        me.video_backbones = []
+        for f, s in zip(feats, Ss):  # a backbone: called as vb(video_values[i], is_image) (merv.py:564), returns its tokens
+            me.video_backbones.append(type("VB", (), {"temporal_resolution": T, "spatial_resolution": s,
+                                                      "__call__": staticmethod((lambda f_: (lambda video, is_image: f_))(f))})())
+        me.tokens_resampled = True
+        me.projectors = projectors
+        me.feature_fusion_type = "cross_attention_avg_lq"
+        me.feature_fusion = fusion_rec
+        input_ids = torch.randint(2, vocab, (B, S), generator=g)
+        input_ids[:, 0] = 1
+        am = torch.ones(B, S, dtype=torch.bool)
+        lab = input_ids.clone()
+        lab[:, : S // 2] = -100
+        for b in range(B):  # ragged right padding
+            pad = b % 3
+            if pad:
+                am[b, S - pad:] = False
+                lab[b, S - pad:] = -100
+        with torch.no_grad():
+            ret = me.forward(input_ids=input_ids, attention_mask=am if with_masks else None,
+                             video_values=[torch.zeros(B, 1)] * 4, labels=lab if with_masks else None,
+                             multimodal_indices=multimodal_indices)
+        assert ret is me.llm_backbone.calls[-1] and ret["input_ids"] is None
+        for i, f in enumerate(feats):
+            out[f"{tag}_feat{i}"] = f.numpy().astype(np.float16)
+        out[f"{tag}_input_ids"] = input_ids.numpy()
+        out[f"{tag}_attention_mask"] = am.numpy()
+        out[f"{tag}_labels"] = lab.numpy()
+        if multimodal_indices is not None:
+            out[f"{tag}_multimodal_indices"] = multimodal_indices.numpy()
+        out[f"{tag}_fused"] = fused_rec["y"].numpy()
+        out[f"{tag}_fusion_weights"] = fused_rec["w"].numpy()
+        out[f"{tag}_inputs_embeds"] = ret["inputs_embeds"].numpy()
+        if with_masks:
+            out[f"{tag}_out_attention_mask"] = ret["attention_mask"].numpy()
+            out[f"{tag}_out_labels"] = ret["labels"].numpy()
+        else:
+            assert ret["attention_mask"] is None and ret["labels"] is None
+        meta[tag] = {"B": B, "S": S, "bos_token_length": 1 if bos_token is not None else 0, "with_masks": with_masks,
+                     "multimodal_indices": None if multimodal_indices is None else multimodal_indices.tolist()}
+
+    run("full", 2, 9, None, "<s>")                                   # fully multimodal batch (multimodal_indices None, :543-545)
+    run("mixed", 4, 7, torch.tensor([0, 2, 3]), "<s>")               # multimodal rows first, unimodal rows padded at the end (:666-719)
+    run("nobos", 1, 6, None, None)                                   # tokenizer without BOS (Qwen2.5; :520-521)
+    run("infer", 1, 8, None, "<s>", with_masks=False)                # generate()-style call: no mask, no labels
+    meta["geometry"] = {"T": T, "llm": llm, "C": list(Cs), "S": list(Ss), "out_size": 8, "embed_dim": 48}
+
+    # ---- generate(): what reaches `video_values` for a given num_frames list (merv.py:796-806)
+    sub = []
+    for num_frames, n_loaded in (([16, 16, 32, 16], 32), ([8, 8, 32, 8], 32), ([16, 16, 32, 12], 32), ([4], 4), ([5, 32, 7], 32), ([16, 16, 32, 16], 20)):
+        seen = {}
+
+        def fake_load_video(video, clip_start_sec=0.0, clip_end_sec=None, num_frames=None, end_frame=None):
+            seen.update(num_frames=num_frames, clip_start_sec=clip_start_sec, clip_end_sec=clip_end_sec, end_frame=end_frame)
+            return torch.arange(n_loaded).view(n_loaded, 1, 1, 1).expand(n_loaded, 3, 2, 2)  # frame k holds the value k
+
+        ref_globals["load_video"] = fake_load_video
+        me = MERV.__new__(MERV)
+        me.device = torch.device("cpu")
+        me.enable_mixed_precision_training = False
+        tok = lambda text, truncation, return_tensors: NS(input_ids=torch.tensor([[1, 5, 6]]))  # noqa: E731
+        tok.pad_token_id = 0
+        tok.decode = lambda ids, skip_special_tokens: " ok "
+        me.llm_backbone = NS(tokenizer=tok, half_precision_dtype=torch.bfloat16)
+        me.video_backbones = [NS(video_transform=(lambda v: v.float()), default_video_resolution=(1,)) for _ in num_frames]
+        text = me.generate("clip.mp4", "prompt", num_frames, end_frame=17, do_sample=False)
+        assert text == "ok"
+        kw = me.generate_kwargs
+        sub.append({"num_frames": num_frames, "frames_loaded": n_loaded, "load_video_num_frames": seen["num_frames"],
+                    "end_frame_forwarded": seen["end_frame"],
+                    "selected": [v[0, :, 0, 0, 0].long().tolist() for v in kw["video_values"]],
+                    "forwarded_kwargs": sorted(k for k in kw if k not in ("video_values",))})
+    meta["generate_subsample"] = sub
+    np.savez_compressed(OUT / "merv_forward.npz", **out)
+    (OUT / "merv_forward.json").write_text(json.dumps(meta, indent=1))
+    print("merv_forward: ok", {k: tuple(v.shape) for k, v in out.items() if k.endswith("inputs_embeds")},
+          [s["selected"][-1][:4] for s in sub])
+
+
+GENERATORS = {"frames": gen_frame_indices, "projfus": gen_projector_fusion, "lb": gen_languagebind, "vivit": gen_vivit,
+              "hf": gen_hf_crosscheck, "prompts": gen_prompts, "preprocess": gen_preprocess,
+              "token_selection": gen_token_selection, "siglip_pool": gen_siglip_pool, "merv_forward": gen_merv_forward}
+
+
+def main(argv):
+    """python3 tools/make_goldens.py [--out DIR] [generator ...]   (no generator names: all of them, in this order)"""
+    global OUT
+    argv = list(argv)
+    if "--out" in argv:
+        i = argv.index("--out")
+        OUT = Path(argv[i + 1])
+        OUT.mkdir(parents=True, exist_ok=True)
+        del argv[i:i + 2]
+    unknown = [a for a in argv if a not in GENERATORS]
+    if unknown:
+        raise SystemExit(f"unknown generator(s) {unknown}; known: {sorted(GENERATORS)}")
+    torch.set_num_threads(8)
+    for name in (argv or list(GENERATORS)):
+        GENERATORS[name]()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
