@@ -41,7 +41,21 @@ BACKBONE_IDS = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-
                 "siglip-vit-b16-224px-all-no-cls"]  # merv/conf/models.py:106-113
 NUM_FRAMES = [16, 16, 32, 16]  # merv/conf/models.py:118
 TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_gemm_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_gemm_traffic.json"
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters; 6.29 TB/s is the measured copy rate)
+# kernel-level profiler classes of libmerv_hip.so (include/merv_hip.h, merv_prof_*): (class, name, bound, kernels)
+KERNEL_CLASSES = [
+    (5, "gemm eight-phase, no activation", "mfma", "gemm_bf16_8phase_kernel<false,0,false>: qkv, proj, fc2, temporal qkv / proj, projector"),
+    (6, "gemm eight-phase + activation epilogue", "mfma", "gemm_bf16_8phase_kernel<false,1|2|3,false>: fc1 (GELU + folded-LayerNorm correction)"),
+    (7, "gemm small tiles", "mfma", "gemm_bf16_kernel<...>: rows the eight-phase launch left over, patch embedding"),
+    (8, "attention, K/V resident", "mfma", "attn_kernel<true,4,2,true,true>: LanguageBind 257 / DINOv2 261 tokens"),
+    (9, "attention, K/V streamed", "mfma", "attn_kernel<true,4,2,false,false>: ViViT 3137 tokens; SigLIP 196 tokens"),
+    (2, "temporal attention", "hbm", "temporal_attn_kernel (LanguageBind, t = 8)"),
+    (3, "LayerNorm", "hbm", "layernorm_kernel (pre_ln, temporal LN, ViViT final LN; the block LNs are folded into GEMMs)"),
+    (10, "LayerNorm statistics", "hbm", "row_stats_kernel + stats_finalize_kernel"),
+    (11, "pool + fusion", "hbm", "pool_kernel, fusion_score_kernel + fusion_mix_kernel"),
+    (12, "data movement", "hbm", "im2col_kernel, prefix_kernel"),
+]
 
 
 def build_models(device, concurrent=True, want_ref=False, ln_fold=True):
@@ -340,9 +354,13 @@ def main():
                                             placement="per_encoder")
                 upe = dpe.synth_unit_pixels(seed=1234)
                 multi_gpu["one_video_one_encoder_per_gpu_latency_ms"] = round(timed(lambda: dpe.forward(upe)) / args.steps * 1e3, 3)
+            multi_gpu["error"] = None
         except Exception as e:  # noqa: BLE001
             multi_gpu["error"] = f"{type(e).__name__}: {e}"
             print(f"[bench] rank {rank}: multi-GPU extra legs failed: {multi_gpu['error']}", file=sys.stderr, flush=True)
+        flags = {k: v for k, v in multi_gpu.items() if k.endswith("_bit_equal_to_single_gpu_path")}
+        print(f"[bench] rank {rank}/{world}: RCCL ranks {dist.get_world_size()}, placed legs bit-equal to the single-GPU path: {flags}, "
+              f"error: {multi_gpu['error']}", file=sys.stderr, flush=True)
 
     # ---- roofline leg: the same K steps again with every GEMM launch bracketed by HIP events on its own stream.
     # Kernel durations are only well defined when kernels do not overlap, so this pass runs the encoders on ONE
@@ -386,6 +404,38 @@ def main():
                     "algorithmic_bytes_per_launch": round(by.value / n.value),
                     "gemm_ms_per_step": round(ms.value / args.steps, 3)}
         lib.merv_prof_reset()
+        # second pass: one event bracket per KERNEL launch, classes that partition the step's kernels (call-level class 0 off:
+        # nested brackets would time each other's event records)
+        path.concurrent = False
+        lib.merv_prof_enable(sum(1 << c for c, *_ in KERNEL_CLASSES))
+        for _ in range(args.steps):
+            step_dp()
+        torch.cuda.synchronize()
+        lib.merv_prof_enable(0)
+        path.concurrent = was
+        by_kernel, tot_ms = [], 0.0
+        for c, name, bound, kernels in KERNEL_CLASSES:
+            lib.merv_prof_read(c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+            if not n.value:
+                continue
+            sec = ms.value * 1e-3
+            ent = {"name": name, "kernels": kernels, "bound": bound, "launches_per_step": round(n.value / args.steps, 1),
+                   "ms_per_step": round(ms.value / args.steps, 3)}
+            if bound == "mfma":
+                peak_k = PEAK_FP8_TFLOPS if (args.mxfp8 and c in (5, 6)) else PEAK_BF16_TFLOPS
+                ent.update({"algorithmic_tflop_per_step": round(fl.value / args.steps / 1e12, 4), "achieved": round(fl.value / sec / 1e12, 1),
+                            "peak": peak_k, "unit": "TFLOP/s", "frac": round(fl.value / sec / 1e12 / peak_k, 4)})
+            else:
+                ent.update({"algorithmic_gb_per_step": round(by.value / args.steps / 1e9, 4), "achieved": round(by.value / sec / 1e9, 1),
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by.value / sec / 1e9 / PEAK_HBM_GBS, 4)})
+            tot_ms += ms.value / args.steps
+            by_kernel.append(ent)
+        lib.merv_prof_reset()
+        if roof is not None:
+            roof["by_kernel"] = by_kernel
+            roof["by_kernel_note"] = (f"one HIP-event bracket per kernel launch, encoders on ONE stream, {args.steps} steps; the classes partition the "
+                                      f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r03_kernel_roofline.json "
+                                      "joins the same classes to a rocprofv3 --kernel-trace of the same command")
 
     parity = cpu = e2e = None
     if rank == 0 and single:
@@ -427,6 +477,12 @@ def main():
         print(json.dumps(line), file=real_stdout, flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    # The extra placed legs never cost the data-parallel headline its line; but when the unit placement IS the headline
+    # (--parallelism units: BASELINE.json configs[2]) a failed or non-bit-equal placed leg fails the run.
+    if multi_gpu is not None and headline_units:
+        bad = multi_gpu.get("error") or [k for k, v in multi_gpu.items() if k.endswith("_bit_equal_to_single_gpu_path") and v is False]
+        if bad:
+            raise SystemExit(f"bench.py --parallelism units: placed legs failed: {bad}")
 
 
 if __name__ == "__main__":

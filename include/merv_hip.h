@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define MERV_ABI_VERSION 1
+/* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged */
+#define MERV_ABI_VERSION 2
 
 /* activation kinds */
 enum { MERV_ACT_NONE = 0, MERV_ACT_GELU_ERF = 1, MERV_ACT_GELU_TANH = 2, MERV_ACT_QUICK_GELU = 3 };
@@ -196,20 +197,9 @@ size_t merv_projector_backward_workspace_bytes(int32_t M, int32_t C, int32_t llm
 int merv_projector_backward(const void *grad_out, const void *pooled, int32_t M, int32_t C, int32_t llm_dim,
                             void *ws, size_t ws_bytes, void *grad_w, float *grad_b, void *stream);
 
-/* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
 /*
- * ---- MXFP8 mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs") ----
- * OCP Microscaling FP8: e4m3 elements, one E8M0 scale per 32 consecutive k (shared exponent floor(log2 amax) - 8, plus
- * one when the scaled block maximum would exceed 448 so that nothing saturates; round-to-nearest-even), consumed by v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA
- * rate. There is no counterpart in the reference (it runs bf16 autocast, merv.py:816): this mode trades the bf16
- * tolerance for throughput and is never the default.
- * merv_quantize_mxfp8: x bf16 [rows, K] (ld elements) -> q [rows, K] bytes + scales (merv_mxfp8_scale_bytes(rows, K)
- *   bytes, in the GEMM's lane order: [K/128][ceil(rows/64)][(kblock%4)*16 + row%16][(row%64)/16]). K % 128 == 0.
- * merv_gemm_mxfp8: C[M,N] bf16 = epilogue(A8 . W8^T), same epilogue arguments as merv_gemm_bf16 (bias, activation,
- *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
- */
-/*
- * LayerNorm folded into the GEMM that consumes it (bf16 path, opt-in): for LN1 -> qkv and LN2 -> fc1 of every block
+ * ---- LayerNorm folded into the GEMM that consumes it (bf16 path; the Python binding enables it by default) ----
+ * For LN1 -> qkv and LN2 -> fc1 of every block
  *   Linear(LayerNorm(x)) = rstd * (x . (W*gamma)^T) - rstd * mean * colsum(W*gamma) + (W . beta + bias)
  * is exact algebra, so the encoder computes only the per-row statistics (one read of x instead of a read + write of the
  * normalised copy) and the GEMM reads the residual stream directly; its epilogue applies the row scale and the rank-1
@@ -222,18 +212,31 @@ size_t merv_encoder_ln_fold_bytes(const merv_encoder *enc);
 int merv_encoder_enable_ln_fold(merv_encoder *enc, void *buf, size_t bytes, void *stream);
 
 /*
+ * ---- MXFP8 mode (BASELINE.json configs[4]: "fp8 MFMA encoder GEMMs"); opt-in, never the default ----
+ * OCP Microscaling FP8: e4m3 elements, one E8M0 scale per 32 consecutive k (shared exponent floor(log2 amax) - 8, plus
+ * one when the scaled block maximum would exceed 448 so that nothing saturates; round-to-nearest-even), consumed by
+ * v_mfma_scale_f32_16x16x128_f8f6f4 at twice the bf16 MFMA rate. There is no counterpart in the reference (it runs bf16
+ * autocast, merv.py:816): this mode trades the bf16 tolerance for throughput.
  * Encoder in MXFP8 mode: the GEMMs of every block (qkv, attention out-projection, fc1, fc2, and LanguageBind's temporal
  * qkv / out-projection) run on MXFP8 operands; LayerNorm statistics, attention, the patch embedding and the residual
- * stream stay bf16 / fp32. The library
- * quantises the block weights it was given at merv_encoder_create into `buf` (merv_encoder_mxfp8_bytes(enc) bytes,
- * 256-byte aligned, owned by the caller for the encoder's lifetime). Call merv_encoder_workspace_bytes AFTER enabling:
- * the workspace grows by the quantised activation buffer. dim and mlp_dim must be multiples of 256 (>= 512).
+ * stream stay bf16 / fp32. The library quantises the block weights it was given at merv_encoder_create into `buf`
+ * (merv_encoder_mxfp8_bytes(enc) bytes, 256-byte aligned, owned by the caller for the encoder's lifetime). Call
+ * merv_encoder_workspace_bytes AFTER enabling: the workspace grows by the quantised activation buffer. dim and mlp_dim
+ * must be multiples of 256 (>= 512).
  */
 size_t merv_encoder_mxfp8_bytes(const merv_encoder *enc);
 int merv_encoder_enable_mxfp8(merv_encoder *enc, void *buf, size_t bytes, void *stream);
 /* Which block GEMMs run on MXFP8 once the mode is enabled: bit 0 qkv (and the temporal qkv), bit 1 attention
  * out-projection (and the temporal one), bit 2 fc1, bit 3 fc2; default 15. The others stay bf16 (accuracy / speed dial). */
 int merv_encoder_set_mxfp8_mask(merv_encoder *enc, int32_t mask);
+
+/* ---- single kernels, exported for parity tests and micro-benchmarks ---- */
+/*
+ * merv_quantize_mxfp8: x bf16 [rows, K] (ld elements) -> q [rows, K] bytes + scales (merv_mxfp8_scale_bytes(rows, K)
+ *   bytes, in the GEMM's lane order: [K/128][ceil(rows/64)][(kblock%4)*16 + row%16][(row%64)/16]). K % 128 == 0.
+ * merv_gemm_mxfp8: C[M,N] bf16 = epilogue(A8 . W8^T), same epilogue arguments as merv_gemm_bf16 (bias, activation,
+ *   LayerScale, residual). K % 256 == 0, K >= 512, N % 256 == 0; lda / ldw in elements (= bytes), multiples of 16.
+ */
 size_t merv_mxfp8_scale_bytes(int32_t rows, int32_t K);
 int merv_quantize_mxfp8(const void *x, int32_t rows, int32_t K, int32_t ld, void *q, void *scales, void *stream);
 int merv_gemm_mxfp8(const void *A8, const void *scale_a, const void *W8, const void *scale_w, void *C, const float *bias,
@@ -290,9 +293,17 @@ int merv_debug_gemm_stats(const void *A, const void *W, void *C, const float *bi
                           int32_t M, int32_t N, int32_t K, int32_t act, float *stats_out, void *stream);
 
 /*
- * Per-launch HIP-event timing (bench.py roofline leg). class bits: 0 GEMM, 1 attention, 2 temporal attention,
- * 3 LayerNorm. While a class is enabled every launch of it is bracketed by two events on its own stream;
- * merv_prof_read sums elapsed ms / launches / algorithmic FLOPs / algorithmic bytes since the last reset.
+ * Per-launch HIP-event timing (bench.py roofline leg). While a class (bit of `class_mask`) is enabled every launch of it is
+ * bracketed by two events on its own stream; merv_prof_read sums elapsed ms / launches / algorithmic FLOPs / algorithmic
+ * bytes since the last reset.
+ *   call level (a merv_gemm_bf16 call may be two kernel launches: eight-phase part + remaining rows):
+ *     0 GEMM calls   1 attention calls   2 temporal attention   3 LayerNorm kernel
+ *   kernel level (one bracket per kernel launch; together with 2 and 3 they partition the kernels of an encoder step):
+ *     5 gemm_bf16_8phase_kernel without activation   6 gemm_bf16_8phase_kernel with an activation epilogue (fc1)
+ *     7 gemm_bf16_kernel (rows the eight-phase launch left over, patch embedding, small problems)
+ *     8 attn_kernel, K / V resident in LDS (257 / 261 tokens)   9 attn_kernel, K / V streamed (196 / 3137 tokens)
+ *     10 row_stats + stats_finalize   11 pool + fusion score + fusion mix   12 im2col / prefix rows / token gather
+ * Enable call-level and kernel-level classes in separate passes (nested brackets would time each other's event records).
  */
 void merv_prof_enable(int32_t class_mask);
 void merv_prof_reset(void);

@@ -51,6 +51,8 @@ class EncoderWeights(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/merv_hip.h declares
 _i32, _i64, _f32, _f64, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+ABI_VERSION = 2  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
+
 SIGNATURES = {
     "merv_last_error": (C.c_char_p, []),
     "merv_abi_version": (C.c_int, []),
@@ -128,8 +130,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export the ABI
         fn.restype = res
         fn.argtypes = args
-    if lib.merv_abi_version() != 1:
-        raise RuntimeError(f"libmerv_hip.so ABI version {lib.merv_abi_version()} != 1")
+    if lib.merv_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmerv_hip.so ABI version {lib.merv_abi_version()} != {ABI_VERSION} (stale build: run `make lib`)")
     _lib = lib
     return lib
 

@@ -63,6 +63,13 @@ class VideoBackbone(nn.Module):
     def forward(self, video_values: torch.Tensor, is_image: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.featurizer.forward(video_values)
 
+    @property
+    def selects_spec_patches(self) -> bool:
+        """True when forward() is exactly the encoder's patch-token output (`featurizer.forward(video)`): the only selection
+        MervVisualPath fuses -- it drives the featurizers directly and sizes the projector from spec.t_out x spec.s_out.
+        Every other registry selection (class token, averages, class-token-first, pooled heads) is served by forward() alone."""
+        return True
+
     def _mean_rows(self, x: torch.Tensor) -> torch.Tensor:
         """[..., R, D] bf16 -> [..., D]: torch.mean(dim=-2) of a bf16 tensor (fp32 accumulation, one rounding), as a HIP kernel."""
         from ._lib import check, ptr
@@ -187,6 +194,10 @@ class LangBindVideoBackbone(VideoBackbone):
         return v.reshape(B, -1, D)
 
     @property
+    def selects_spec_patches(self) -> bool:
+        return self.token == "noclass"
+
+    @property
     def num_patches(self) -> int:  # languagebind/__init__.py:113-126 (classemb-at-first: the class token is not counted)
         return self.num_frames * {None: 257, "average": 1, "classemb": 1, "noclass": 256, "classemb-at-first": 256}[self.token]
 
@@ -236,6 +247,10 @@ class DinoV2VideoBackbone(VideoBackbone):
         return torch.cat([cls, patches], 1)
 
     @property
+    def selects_spec_patches(self) -> bool:
+        return "all-tokens" in self.identifier
+
+    @property
     def num_patches(self) -> int:  # dinov2_video.py:164-170, quirks kept ("all-token-with-cls" does not contain "all-tokens")
         if "classemb-at-first" in self.identifier or "all-tokens" in self.identifier:
             return self.num_frames * self.spec.s_out
@@ -274,6 +289,10 @@ class ViVITVideoBackbone(VideoBackbone):
         if "all-no-cls" in ident:  # every second of the 16 tubelet slots
             return v[:, 1:].reshape(B, 16, 14, 14, D)[:, ::2].reshape(B, 8 * 14 * 14, D)
         return v  # all-tokens, classemb-at-first-16frames: neither branch of vivit.py:106-117 fires
+
+    @property
+    def selects_spec_patches(self) -> bool:
+        return "all-no-cls-16frames" in self.video_backbone_id
 
     @property
     def num_patches(self) -> int:  # vivit.py:128-142
@@ -358,6 +377,10 @@ class SiglipVideoBackbone(VideoBackbone):
             h = ops.gemm(ops.layernorm(y, P["norm_w"], P["norm_b"], 1e-6), P["fc1_w"], P["fc1_b"], act="gelu_erf")
             out = ops.gemm(h, P["fc2_w"], P["fc2_b"], res=y)  # x + mlp(norm(x)); latent_len = 1: token 0 is the row
         return out.view(B, -1, D)
+
+    @property
+    def selects_spec_patches(self) -> bool:
+        return not self.class_token
 
     @property
     def num_patches(self) -> int:  # siglip.py:161-166

@@ -679,6 +679,7 @@ template <int NW, int QPW, bool XQ = false, bool RES = false>
 static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
     const int rows = NW * QPW * 32;
     dim3 grid(XQ ? 1 : (a.L + rows - 1) / rows, a.heads, a.nseq);
+    ProfScope pk(RES ? PROF_K_ATTN_RES : PROF_K_ATTN_STREAM, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
     if (RES || use_vtr())
         hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ, RES>), grid, dim3(NW * 64), 0, s, a);
     else if constexpr (!RES)

@@ -833,6 +833,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
                  2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (a.res ? 2 : 1)));
     auto dispatch = [&](const GemmArgs& g, bool eight_phase) -> hipError_t {
+        ProfScope pk(eight_phase ? (g.act == ACT_NONE ? PROF_K_GEMM8_PLAIN : PROF_K_GEMM8_ACT) : PROF_K_GEMM_SMALL, s,
+                     2.0 * g.M * g.N * g.K, 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N * (g.res ? 2 : 1)));
         switch (g.act) {
             case ACT_NONE: return eight_phase ? launch_8phase<ACT_NONE>(g, s) : launch_act<ACT_NONE>(g, s);
             case ACT_GELU_ERF: return eight_phase ? launch_8phase<ACT_GELU_ERF>(g, s) : launch_act<ACT_GELU_ERF>(g, s);

@@ -20,14 +20,14 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
-void prof_begin_slow(int cls, hipStream_t s, double flops, double bytes) {
+int prof_begin_slow(int cls, hipStream_t s, double flops, double bytes) {
     Rec r{get_event(), get_event(), cls, flops, bytes};
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
+    return (int)g_recs.size() - 1;
 }
-void prof_end_slow(int cls, hipStream_t s) {
-    (void)cls;
-    if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, s);
+void prof_end_slow(int idx, hipStream_t s) {
+    if (idx >= 0 && idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].b, s);
 }
 }  // namespace merv
 

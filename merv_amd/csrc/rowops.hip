@@ -428,6 +428,7 @@ hipError_t launch_im2col(const Im2colArgs& a, hipStream_t s) {
     const int hp = a.img / a.patch;
     const long long total = (long long)a.B * (a.frames / a.tt) * hp * hp * (a.kpad / 8);
     if (total <= 0) return hipSuccess;
+    ProfScope pk(PROF_K_MOVE, s, 0.0, (double)a.B * a.frames * 3.0 * a.img * a.img * (a.pix_is_bf16 ? 2 : 4) + 16.0 * total);
     if (a.pix_is_bf16)
         hipLaunchKernelGGL(im2col_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, a);
     else
@@ -438,6 +439,7 @@ hipError_t launch_im2col(const Im2colArgs& a, hipStream_t s) {
 hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
     const long long total = (long long)a.nseq * a.npre * (a.D / 8);
     if (total <= 0) return hipSuccess;
+    ProfScope pk(PROF_K_MOVE, s, 0.0, 16.0 * total);
     hipLaunchKernelGGL(prefix_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsFinalizeArgs p
 hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.nparts <= 0 || !a.parts || !a.stats) return hipErrorInvalidValue;
+    ProfScope pk(PROF_K_STATS, s, 0.0, 8.0 * a.M * (double)a.nparts + 8.0 * a.M);
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 15) / 16), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -480,6 +483,7 @@ hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s) {
 hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.D % 8 != 0 || a.D > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
+    ProfScope pk(PROF_K_STATS, s, 0.0, 2.0 * a.M * (double)a.D + 8.0 * a.M);
     hipLaunchKernelGGL(row_stats_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -493,6 +497,7 @@ hipError_t launch_ln_fold(const LnFoldArgs& a, hipStream_t s) {
 hipError_t launch_gather_tokens(const GatherTokensArgs& a, hipStream_t s) {
     const long long total = (long long)a.B * a.T * a.S * (a.D / 8);
     if (total <= 0) return hipSuccess;
+    ProfScope pk(PROF_K_MOVE, s, 0.0, 32.0 * total);
     hipLaunchKernelGGL(gather_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -516,6 +521,7 @@ hipError_t launch_pool(const PoolArgs& a, hipStream_t s) {
     if (a.C % 8 != 0 || a.Ho <= 0 || a.S < a.Ho) return hipErrorInvalidValue;
     const long long total = (long long)a.B * a.T * a.Ho * a.Ho * (a.C / 8);
     if (total <= 0) return hipSuccess;
+    ProfScope pk(PROF_K_POOLFUSE, s, 0.0, 2.0 * a.B * a.T * ((double)a.S * a.S + (double)a.Ho * a.Ho) * a.C);
     hipLaunchKernelGGL(pool_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -526,6 +532,9 @@ hipError_t launch_fusion(const FusionArgs& a, hipStream_t s) {
     if (a.E < 1 || a.E > 8 || a.C % 8 != 0) return hipErrorInvalidValue;
     if (a.B <= 0) return hipSuccess;
     const int nchunk = (a.T + FUSE_ROWS - 1) / FUSE_ROWS;
+    // algorithmic bytes: every V_e read once + the fused tokens written (41.9 MB per video); the two-kernel form
+    // reads V twice (score pass, mix pass), which is what `achieved` is priced against
+    ProfScope pk(PROF_K_POOLFUSE, s, 0.0, 2.0 * (a.E + 1) * (double)a.B * a.T * a.C);
     hipLaunchKernelGGL(fusion_score_kernel, dim3(nchunk, a.E, a.B), dim3(256), 0, s, a);
     const long long per_b = (long long)a.T * (a.C / 8);
     int gx = (int)((per_b + 255) / 256);

@@ -57,8 +57,13 @@ class DistributedVisualPath:
             raise ValueError(f"unknown placement `{placement}`")
         if replicate_fusion and exchange != "all_gather":
             raise ValueError("replicate_fusion (every rank fuses every video) needs the all_gather exchange")
-        if (videos_per_rank is None) == (n_videos is None) and not replicate_fusion:
-            raise ValueError("give videos_per_rank (throughput form) or n_videos with replicate_fusion (latency form)")
+        # two forms, nothing in between: throughput (videos_per_rank, every rank fuses its own videos) or latency (n_videos
+        # spread over all ranks, every rank fuses all of them)
+        if replicate_fusion:
+            if n_videos is None or videos_per_rank is not None:
+                raise ValueError("latency form: give n_videos (and no videos_per_rank) together with replicate_fusion")
+        elif videos_per_rank is None or n_videos is not None:
+            raise ValueError("throughput form: give videos_per_rank (and no n_videos); n_videos needs replicate_fusion")
         self.local, self.specs = local, list(specs)
         self.world, self.rank = world, rank
         self.E = len(self.specs)

@@ -90,6 +90,10 @@ class LlamaBackbone:
         self.embed_dim = cfg.hidden_size
         self.config = cfg
         self.identifier, self.family = identifier, family
+        # merv.py:520-521 asks the TOKENIZER whether a BOS is prepended ("QWEN2.5-7B-INSTRUCT has no BOS token"); Qwen2.5's
+        # config.json still carries bos_token_id = 151643, so the config is not the test. Used when no tokenizer object is
+        # attached (vidlm.bos_token_length).
+        self.prepends_bos = family != "qwen2"
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -124,17 +128,36 @@ class LlamaBackbone:
     def embed_input_ids(self, input_ids: torch.LongTensor) -> torch.Tensor:
         return self.llm.get_input_embeddings()(input_ids)
 
+    def _needs_hf_decode(self, total_len: int) -> bool:
+        """True when the model has a feature neither static-cache decoder implements, so generation must stay on the HF
+        module's own forward: sliding-window attention that would actually clip at this length (Mistral-v0.1-style
+        `sliding_window`, Qwen2 with `use_sliding_window`), or biases on the MLP projections."""
+        cfg = self.config
+        win = getattr(cfg, "sliding_window", None)
+        if win is not None and getattr(cfg, "use_sliding_window", True) and total_len > int(win):
+            return True
+        mlp = self.llm.model.layers[0].mlp
+        return any(getattr(getattr(mlp, n, None), "bias", None) is not None for n in ("gate_proj", "up_proj", "down_proj"))
+
     @torch.inference_mode()
     def generate_from_embeds(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 32, do_sample: bool = False,
                              temperature: float = 1.0, eos_token_id: Optional[int] = None,
                              generator: Optional[torch.Generator] = None, use_graph: bool = True, top_k: int = 0,
-                             top_p: float = 1.0, repetition_penalty: float = 1.0, min_new_tokens: int = 0,
-                             use_hip_decode: bool = True) -> torch.LongTensor:
+                             top_p: Optional[float] = 1.0, repetition_penalty: Optional[float] = 1.0, min_new_tokens: int = 0,
+                             use_hip_decode: bool = True, prompt_ids: Optional[torch.LongTensor] = None) -> torch.LongTensor:
         """Prefill on `inputs_embeds` [B, S, D] (merv.py:723-734), then decode token by token on the KV cache
         (merv.py:524-538). Returns the new token ids [B, <= max_new_tokens]. Decoding controls are the subset of HF
         `generate` kwargs the reference's scripts pass through (merv.py:818-825): greedy or sampling with `temperature`,
-        `top_k`, `top_p`, plus `repetition_penalty` over the generated tokens (HF's logits processors, same order:
-        penalty -> temperature -> top-k -> top-p)."""
+        `top_k`, `top_p`, plus `repetition_penalty` (HF's logits processors, same order: penalty -> temperature -> top-k ->
+        top-p). The reference hands `input_ids` to HF generate (merv.py:819), so HF's RepetitionPenaltyLogitsProcessor penalises
+        the PROMPT's tokens as well as the generated ones: pass them as `prompt_ids` [B, S_text] (MERV.generate does) to get the
+        same set; without them only generated tokens are penalised. `None` for top_p / repetition_penalty / top_k means "off",
+        as in HF's GenerationConfig."""
+        top_p = 1.0 if top_p is None else float(top_p)
+        repetition_penalty = 1.0 if repetition_penalty is None else float(repetition_penalty)
+        top_k = int(top_k or 0)
+        if use_graph and self._needs_hf_decode(inputs_embeds.shape[1] + max_new_tokens + 1):
+            use_graph = False  # the static-cache decoders implement neither sliding-window attention nor MLP biases
         if use_graph and inputs_embeds.is_cuda and inputs_embeds.shape[1] + max_new_tokens + 1 <= self.config.max_position_embeddings:
             # static-cache prefill + hipGraph-replayed decode steps (StaticDecoder above)
             need = inputs_embeds.shape[1] + max_new_tokens + 1
@@ -164,8 +187,9 @@ class LlamaBackbone:
             if eos_token_id is not None and i < min_new_tokens:  # HF MinLength / MinNewTokensLength processors
                 logits = logits.clone()
                 logits[:, eos_token_id] = float("-inf")
-            if repetition_penalty != 1.0 and new_tokens:  # HF RepetitionPenaltyLogitsProcessor over the tokens generated so far
-                prev = torch.stack(new_tokens, 1)
+            if repetition_penalty != 1.0 and (new_tokens or prompt_ids is not None):  # HF RepetitionPenaltyLogitsProcessor
+                seen = ([prompt_ids.to(logits.device)] if prompt_ids is not None else []) + ([torch.stack(new_tokens, 1)] if new_tokens else [])
+                prev = torch.cat(seen, 1)
                 sel = logits.gather(1, prev)
                 logits = logits.scatter(1, prev, torch.where(sel < 0, sel * repetition_penalty, sel / repetition_penalty))
             if do_sample:
@@ -334,8 +358,9 @@ class HipDecoder(StaticDecoder):
         hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
         p = next(hf_model.parameters())
         lyr = hf_model.model.layers[0]
+        mlp_bias = any(getattr(getattr(lyr.mlp, n, None), "bias", None) is not None for n in ("gate_proj", "up_proj", "down_proj"))
         return (batch == 1 and hd == 128 and p.is_cuda and p.dtype == torch.bfloat16 and lyr.self_attn.o_proj.bias is None
-                and getattr(lyr.mlp.gate_proj, "bias", None) is None and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0)
+                and not mlp_bias and cfg.hidden_size % 8 == 0 and cfg.intermediate_size % 8 == 0)
 
     def __init__(self, hf_model, max_len: int, batch: int = 1) -> None:
         super().__init__(hf_model, max_len, batch)

@@ -208,7 +208,8 @@ def training_forward(vidlm: MERV, input_ids: torch.Tensor, attention_mask: torch
         with torch.autocast("cuda", dtype=torch.bfloat16):  # same mixed-precision context as the multimodal branch
             out = llm.llm(input_ids=input_ids, attention_mask=attention_mask, labels=labels)
         return out.loss, out.logits, None
-    bos = 1 if getattr(llm.config, "bos_token_id", None) is not None else 0
+    from .vidlm import bos_token_length
+    bos = bos_token_length(llm, getattr(vidlm, "tokenizer", None))  # merv.py:520-521: the tokenizer decides
     fused, w = encode_trainable(vidlm, [v[multimodal_indices] for v in video_values])  # merv.py:563-566
     emb = llm.llm.get_input_embeddings()(input_ids)
     emb_all, am_all, lab_all = assemble_training_batch(emb, fused, attention_mask, labels, multimodal_indices, bos)

@@ -21,12 +21,34 @@ from .visual_path import MervVisualPath
 IGNORE_INDEX = -100
 
 
+def bos_token_length(llm_backbone, tokenizer=None) -> int:
+    """merv.py:520-521: `1 if self.llm_backbone.tokenizer.bos_token is not None else 0` ("QWEN2.5-7B-INSTRUCT has no BOS
+    token"). Decided from the TOKENIZER, as the reference does -- Qwen2.5's config.json carries bos_token_id = 151643 although
+    its tokenizer prepends nothing, so config.bos_token_id is not the test. Order: the tokenizer's `bos_token` attribute when a
+    tokenizer is attached (HF tokenizers, HFTokenizerAdapter), else the backbone's per-family `prepends_bos` flag (LLM registry;
+    False for the qwen2 family), else True."""
+    tok = tokenizer if tokenizer is not None else getattr(llm_backbone, "tokenizer", None)
+    inner = getattr(tok, "tok", tok)  # HFTokenizerAdapter wraps the HF object as `.tok`
+    if inner is not None and hasattr(inner, "bos_token"):
+        return 1 if inner.bos_token is not None else 0
+    return 1 if getattr(llm_backbone, "prepends_bos", True) else 0
+
+
 class MERVVisual(nn.Module):
     def __init__(self, video_backbones: Sequence[VideoBackbone], llm_dim: int = 4096, arch_specifier: str = "3davg+linear",
                  feature_fusion: Optional[str] = "cross_attention_avg_lq", projector_token_length: int = 64,
                  visual_feature_length: int = 1024, concurrent_streams: bool = True) -> None:
         super().__init__()
         self.video_backbones = list(video_backbones)  # frozen, not registered as sub-modules (merv.py:315-381)
+        # The visual path drives the encoders' featurizers directly (patch tokens, projector geometry spec.t_out x spec.s_out);
+        # a backbone id whose forward() selects something else (class token, averages, class-token-first, pooled SigLIP) would
+        # silently be fused as plain patches. Those ids are served by VideoBackbone.forward() alone; MERV refuses them.
+        for vb in self.video_backbones:
+            if not getattr(vb, "selects_spec_patches", True):
+                raise NotImplementedError(
+                    f"MERV on the HIP path fuses patch-token backbones only; `{vb.identifier}` selects other tokens "
+                    f"(num_patches={vb.num_patches}). Use its forward() directly, or a patch-token id "
+                    "(languagebind-video-noclass, dinov2-video-all-tokens, vivit-google-b-all-no-cls-16frames, siglip-vit-b16-224px-all-no-cls).")
         self.feature_fusion_type = feature_fusion
         torch.manual_seed(self.video_backbones[0].embed_dim)  # merv.py:87: projector-init consistency
         self.arch_specifier = arch_specifier
@@ -201,7 +223,8 @@ class MERV(MERVVisual):
         end_frame = kwargs.pop("end_frame", None)
         max_new = kwargs.pop("max_new_tokens", 32)
         gen = dict(max_new_tokens=max_new, do_sample=kwargs.pop("do_sample", False), temperature=kwargs.pop("temperature", 1.0),
-                   top_k=kwargs.pop("top_k", 0) or 0, top_p=kwargs.pop("top_p", 1.0), repetition_penalty=kwargs.pop("repetition_penalty", 1.0))
+                   top_k=kwargs.pop("top_k", 0) or 0, top_p=kwargs.pop("top_p", 1.0) or 1.0,
+                   repetition_penalty=kwargs.pop("repetition_penalty", 1.0) or 1.0)
         # HF generate kwargs the reference forwards (merv.py:818-825) that change nothing here, or that this explicit
         # prefill + decode loop does not implement: the former are accepted, the latter fail loudly instead of silently
         # decoding differently from the reference's eval scripts
@@ -234,9 +257,10 @@ class MERV(MERVVisual):
         else:  # merv.py:807-811
             video_values = [torch.zeros(vb.default_video_resolution, device=dev).unsqueeze(0) for vb in self.video_backbones]
         emb = self.llm_backbone.embed_input_ids(input_ids)
-        bos = 1 if getattr(self.llm_backbone.config, "bos_token_id", None) is not None else 0  # merv.py:521
+        bos = bos_token_length(self.llm_backbone, self.tokenizer)  # merv.py:520-521
         fused_emb, _, _, weights = self.forward_visual(video_values, emb, bos_token_length=bos)
-        ids = self.llm_backbone.generate_from_embeds(fused_emb, eos_token_id=getattr(self.llm_backbone.config, "eos_token_id", None), **gen)
+        ids = self.llm_backbone.generate_from_embeds(fused_emb, eos_token_id=getattr(self.llm_backbone.config, "eos_token_id", None),
+                                                     prompt_ids=input_ids, **gen)  # HF penalises the prompt's ids too (merv.py:819)
         self.last_fusion_weights = weights
         if self.tokenizer is not None and hasattr(self.tokenizer, "decode"):
             return self.tokenizer.decode(ids[0].tolist()).strip()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libmerv_hip.so does not export {n}"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.merv_abi_version() == 1
+    assert lib.merv_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -467,3 +467,58 @@ def test_temporal_subsample_matches_the_reference_generate_body():
     for c in json.loads((G / "merv_forward.json").read_text())["generate_subsample"]:
         for nf, sel in zip(c["num_frames"], c["selected"]):
             assert temporal_subsample(c["frames_loaded"], max(c["num_frames"]), nf) == sel, c
+
+
+def test_merv_refuses_backbones_whose_forward_is_not_the_patch_selection():
+    """the visual path drives featurizers directly, so an id that selects class tokens / averages / a pooled head
+    must not be fused silently as plain patches (merv.py:563-585 calls vb.forward and reshapes by vb's own resolutions)."""
+    from merv_amd import backbones as BB
+    from merv_amd.vidlm import MERVVisual
+
+    def bare(cls, **attrs):
+        o = object.__new__(cls)
+        torch.nn.Module.__init__(o)
+        for k, v in attrs.items():
+            setattr(o, k, v)
+        return o
+    sel = {
+        "languagebind-video-noclass": bare(BB.LangBindVideoBackbone, token="noclass").selects_spec_patches,
+        "languagebind-video-classemb": bare(BB.LangBindVideoBackbone, token="classemb").selects_spec_patches,
+        "languagebind-video": bare(BB.LangBindVideoBackbone, token=None).selects_spec_patches,
+        "dinov2-video-all-tokens": bare(BB.DinoV2VideoBackbone, identifier="dinov2-video-all-tokens").selects_spec_patches,
+        "dinov2-video": bare(BB.DinoV2VideoBackbone, identifier="dinov2-video").selects_spec_patches,
+        "dinov2-video-all-token-with-cls": bare(BB.DinoV2VideoBackbone, identifier="dinov2-video-all-token-with-cls").selects_spec_patches,
+        "vivit-google-b-all-no-cls-16frames": bare(BB.ViVITVideoBackbone, video_backbone_id="vivit-google-b-all-no-cls-16frames").selects_spec_patches,
+        "vivit-google-b-all-no-cls": bare(BB.ViVITVideoBackbone, video_backbone_id="vivit-google-b-all-no-cls").selects_spec_patches,
+        "vivit-google-b-cls-token": bare(BB.ViVITVideoBackbone, video_backbone_id="vivit-google-b-cls-token").selects_spec_patches,
+        "siglip-vit-b16-224px-all-no-cls": bare(BB.SiglipVideoBackbone, class_token=False).selects_spec_patches,
+        "siglip-vit-b16-224px": bare(BB.SiglipVideoBackbone, class_token=True).selects_spec_patches,
+    }
+    assert [k for k, v in sel.items() if v] == ["languagebind-video-noclass", "dinov2-video-all-tokens",
+                                                "vivit-google-b-all-no-cls-16frames", "siglip-vit-b16-224px-all-no-cls"]
+    vb = bare(BB.LangBindVideoBackbone, token="classemb", identifier="languagebind-video-classemb", num_frames=16)
+    with pytest.raises(NotImplementedError, match="patch-token backbones only"):
+        MERVVisual([vb])
+
+
+def test_bos_token_length_is_decided_by_the_tokenizer_like_the_reference():
+    """merv.py:520-521. Qwen2.5: config.bos_token_id = 151643 but tokenizer.bos_token is None -> 0."""
+    from types import SimpleNamespace as NS
+    from merv_amd.llm import HFTokenizerAdapter, qwen25_7b_config
+    from merv_amd.vidlm import bos_token_length
+    assert qwen25_7b_config()["bos_token_id"] is not None  # the trap
+    qwen = NS(config=NS(bos_token_id=151643), prepends_bos=False)
+    llama = NS(config=NS(bos_token_id=1), prepends_bos=True)
+    assert bos_token_length(qwen) == 0 and bos_token_length(llama) == 1
+    assert bos_token_length(llama, HFTokenizerAdapter(NS(bos_token=None))) == 0      # the tokenizer wins over the family flag
+    assert bos_token_length(qwen, HFTokenizerAdapter(NS(bos_token="<s>"))) == 1
+    assert bos_token_length(llama, NS(bos_token=None)) == 0                          # a bare HF tokenizer
+    assert bos_token_length(qwen, lambda text: [1, 2]) == 0                          # callable without the attribute -> family flag
+
+
+def test_distributed_path_argument_forms_are_validated():
+    from merv_amd.distributed import DistributedVisualPath
+    for kw in (dict(n_videos=2), dict(videos_per_rank=2, n_videos=2), dict(), dict(videos_per_rank=2, n_videos=1, replicate_fusion=True, exchange="all_gather"),
+               dict(replicate_fusion=True, exchange="all_gather")):
+        with pytest.raises(ValueError, match="form"):
+            DistributedVisualPath(None, [], 2, 0, **kw)
