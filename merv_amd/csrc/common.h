@@ -74,24 +74,41 @@ MERV_DEVICE float activate(float x) {
 // measured 22-30 % of an fc1 launch before this form (tools/fc1_probe.py).
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// a * b and fma(a, b, 0.5) clamped to [0, 1] by the VOP3 output modifier of the instruction itself (written as fmed3(.., 0, 1) hipcc
+// SLP-packs the product into a v_pk_mul_f32 and then spends a v_max_f32 .. clamp per element on the clamp)
+MERV_DEVICE float mul_clamp01(float a, float b) {
+    float r;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+MERV_DEVICE float fma_half_clamp01(float a, float b) {  // clamp(a * b + 0.5): 0.5 is an inline constant of the encoding
+    float r;
+    asm("v_fma_f32 %0, %1, %2, 0.5 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Phi(x) - 0.5 = (x/c) Q((x/c)^2) on |x| <= c = 4.25: degree-8 minimax for the absolute error of x Phi(x) (see activate2)
+__device__ constexpr float GELU_Q[9] = {1.6949809279f, -5.0811122567f, 13.475584255f, -27.024260417f, 40.026775381f,
+                                        -42.054740051f, 29.308115773f, -12.034233795f, 2.1888832456f};
+
 template <int ACT>
 MERV_DEVICE f32x2 activate2(f32x2 x) {
     if constexpr (ACT == ACT_GELU_ERF) {
-        // gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - 0.5 |x| erfc(|x|/sqrt2); erfc by A&S 7.1.26 (|err| <= 1.5e-7):
-        // erfc(z) = (a1 t + .. + a5 t^5) exp(-z^2), t = 1 / (1 + 0.3275911 z). No compare / select, relative accuracy
-        // kept on the negative tail. Coefficients carry the factor 0.5.
-        const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
-        const f32x2 d = ax * (0.3275911f * 0.70710678118654752440f) + 1.0f;
-        const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        f32x2 p = t * (0.5f * 1.061405429f) + (0.5f * -1.453152027f);
-        p = p * t + (0.5f * 1.421413741f);
-        p = p * t + (0.5f * -0.284496736f);
-        p = p * t + (0.5f * 0.254829592f);
-        p = p * t;
-        const f32x2 u = (x * x) * (-0.5f * 1.4426950408889634f);  // -z^2 log2(e)
-        const f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
-        const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
-        return r - (ax * p) * e;
+        // gelu(x) = x Phi(x), Phi(x) = 0.5 + 0.5 erf(x / sqrt 2), with NO transcendental instruction (round 3): on [-c, c],
+        // c = 4.25, Phi(x) - 0.5 = (x/c) Q((x/c)^2) with Q the degree-8 minimax polynomial for the absolute error of x Phi(x)
+        // (LP fit on 6000 Chebyshev nodes: 1.6e-5; evaluated in fp32 incl. the cut-off 4.6e-5 -- bf16 resolves 6e-5 at |y| = 0.016
+        // and 3.9e-3 at |y| = 1); outside, t = clamp((x/c)^2) = 1 makes 0.5 + (x/c) Q(1) overshoot [0, 1] and the second clamp
+        // returns exactly 0 or 1 (true Phi(-4.25) = 1.07e-5). Both clamps are the VOP3 output modifier of a v_mul / v_fma, i.e.
+        // free. 11 packed + 4 plain VALU per pair against v_rcp + v_exp + 11 packed + 2 v_max of the erfc form this replaces
+        // (A&S 7.1.26, still the scalar activate<> above): in the epilogue all eight waves of a block are in VALU code with the
+        // matrix pipe idle, and the erfc form cost a LanguageBind fc1 launch 90 us of 541 (tools/probes/fc1_epilogue_cost.py).
+        const f32x2 xs = x * (1.0f / 4.25f);
+        const f32x2 t = {mul_clamp01(xs[0], xs[0]), mul_clamp01(xs[1], xs[1])};
+        f32x2 q = t * GELU_Q[8] + GELU_Q[7];
+#pragma unroll
+        for (int k = 6; k >= 0; --k) q = q * t + GELU_Q[k];
+        const f32x2 phi = {fma_half_clamp01(xs[0], q[0]), fma_half_clamp01(xs[1], q[1])};
+        return x * phi;
     } else if constexpr (ACT == ACT_GELU_TANH) {
         // 0.5 x (1 + tanh(u)) = x * sigmoid(2u) = x / (1 + exp(-2u)),  u = 0.7978845608 x (1 + 0.044715 x^2)
         const f32x2 q = (x * x) * 0.044715f + 1.0f;
@@ -106,6 +123,32 @@ MERV_DEVICE f32x2 activate2(f32x2 x) {
         return x * rc;
     } else {
         return x;
+    }
+}
+
+// Two pairs at once. For the erf GELU the two Horner chains are written interleaved: a v_pk_fma_f32 whose operand was written by
+// the instruction right before it needs a wait state (hipcc pads every step of a lone chain with s_nop 0, and under the register
+// pressure of the GEMM epilogue it does not interleave two activate2 calls by itself).
+template <int ACT>
+MERV_DEVICE void activate4(f32x2& a, f32x2& b) {
+    if constexpr (ACT == ACT_GELU_ERF) {
+        const f32x2 xa = a * (1.0f / 4.25f), xb = b * (1.0f / 4.25f);
+        const f32x2 ta = {mul_clamp01(xa[0], xa[0]), mul_clamp01(xa[1], xa[1])};
+        const f32x2 tb = {mul_clamp01(xb[0], xb[0]), mul_clamp01(xb[1], xb[1])};
+        f32x2 qa = ta * GELU_Q[8] + GELU_Q[7];
+        f32x2 qb = tb * GELU_Q[8] + GELU_Q[7];
+#pragma unroll
+        for (int k = 6; k >= 0; --k) {
+            qa = qa * ta + GELU_Q[k];
+            qb = qb * tb + GELU_Q[k];
+        }
+        const f32x2 pa = {fma_half_clamp01(xa[0], qa[0]), fma_half_clamp01(xa[1], qa[1])};
+        const f32x2 pb = {fma_half_clamp01(xb[0], qb[0]), fma_half_clamp01(xb[1], qb[1])};
+        a = a * pa;
+        b = b * pb;
+    } else {
+        a = activate2<ACT>(a);
+        b = activate2<ACT>(b);
     }
 }
 

@@ -98,6 +98,9 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     // folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]. Row statistics (the row of acc[i][j] is j * 16 + frow of its
     // part) and column sums are requested HERE, ahead of the staging barrier and the residual loads, so their latency is hidden
     // (loaded at first use they stalled every part of every tile for a full global-load round trip: +3 % on qkv / fc1 launches)
+    // Without a fold the same arithmetic runs on {rstd, -mean rstd} = {1, 0} and colsum = 0 -- acc * 1 + 0 * 0 is acc exactly -- so
+    // the loop below has no per-element select on the (runtime, wave-uniform) pointer: hipcc turned `if (p.row_stats)` around the
+    // fma into two v_cndmask per pair on top of both candidates.
     float2 rs_all[MSPLIT][MI];
     float4 cs4[NI];
     if (p.row_stats) {
@@ -112,6 +115,13 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             }
 #pragma unroll
         for (int i = 0; i < NI; ++i) cs4[i] = *(const float4*)(p.ln_colsum + wn0 + i * 16 + (elane >> 4) * 4);
+    } else {
+#pragma unroll
+        for (int part = 0; part < MSPLIT; ++part)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) rs_all[part][j] = float2{1.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NI; ++i) cs4[i] = float4{0.f, 0.f, 0.f, 0.f};
     }
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
 #pragma unroll
@@ -151,16 +161,15 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             const float4 cs = cs4[i];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                f32x4 v = acc[i][part * MI + j];
-                if (p.row_stats) {
-                    const float2 rs = rs_all[part][j];
-                    v[0] = fmaf(v[0], rs.x, rs.y * cs.x);
-                    v[1] = fmaf(v[1], rs.x, rs.y * cs.y);
-                    v[2] = fmaf(v[2], rs.x, rs.y * cs.z);
-                    v[3] = fmaf(v[3], rs.x, rs.y * cs.w);
-                }
-                const f32x2 lo = activate2<ACT>(f32x2{v[0], v[1]} + f32x2{bias4[i].x, bias4[i].y}) * f32x2{ls4[i].x, ls4[i].y};
-                const f32x2 hi = activate2<ACT>(f32x2{v[2], v[3]} + f32x2{bias4[i].z, bias4[i].w}) * f32x2{ls4[i].z, ls4[i].w};
+                const f32x4 v = acc[i][part * MI + j];
+                const float2 rs = rs_all[part][j];
+                // fma(acc, rstd, (-mean rstd) * colsum) + bias: the same roundings as the scalar form of rounds 1-2
+                const f32x2 rx = {rs.x, rs.x};
+                f32x2 lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, rx, f32x2{cs.x, cs.y} * rs.y) + f32x2{bias4[i].x, bias4[i].y};
+                f32x2 hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, rx, f32x2{cs.z, cs.w} * rs.y) + f32x2{bias4[i].z, bias4[i].w};
+                activate4<ACT>(lo, hi);
+                lo = lo * f32x2{ls4[i].x, ls4[i].y};
+                hi = hi * f32x2{ls4[i].z, ls4[i].w};
                 u32x2 o;
                 o[0] = pack2bf(lo[0], lo[1]);
                 o[1] = pack2bf(hi[0], hi[1]);
@@ -779,6 +788,12 @@ int choose_variant(const GemmArgs& a) {
     if (g_gemm_variant) return g_gemm_variant;
     const long tiles = (long)((a.M + 255) / 256) * (a.N / 128);
     if (tiles >= 160) return 4;
+    // a few hundred rows (what the eight-phase launch leaves of LanguageBind / DINOv2 at 16 videos: 256 / 1280 rows): the
+    // launch is the latency of ONE block's K-loop, so the tile that fills the chip with the most, smallest blocks wins --
+    // 64 x 128 with four waves of 32 x 64 (half the MFMAs per K-step of the 128 x 128 block, 4-deep ring) while that is at most
+    // one block per CU: 9.0-9.9 us against 12.9-14.2 at K = 1024 and 23.4 against 36.9 at K = 4096 (tools/probes/gemm_remainder.py)
+    const long blocks64 = (long)((a.M + 63) / 64) * (a.N / 128);
+    if (blocks64 <= num_cus()) return 9;
     // few blocks: at most one 128x128 block per CU, so co-residency cannot hide the DMA latency of a 2-deep ring
     // (a lone block then runs ~1.3 us per K-step); a 4-deep ring keeps three tiles in flight instead
     const long small_tiles = (long)((a.M + 127) / 128) * (a.N / 128);
@@ -807,6 +822,7 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
         case 3: return launch_cfg<256, 128, 4, 2, 3, false, ACT>(a, s);
         case 4: return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);
         case 6: return launch_cfg<128, 128, 2, 2, 4, false, ACT>(a, s);
+        case 9: return launch_cfg<64, 128, 2, 2, 4, false, ACT>(a, s);
         case 7:
             if (a.N % 256 == 0 && (a.K / BK) % 2 == 0 && a.K / BK >= 4) return launch_8phase<ACT>(a, s);
             return launch_cfg<256, 128, 4, 2, 3, true, ACT>(a, s);

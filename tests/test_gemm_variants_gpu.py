@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 # variant 0 = automatic choice, incl. the split between the eight-phase kernel (complete rounds) and a smaller-tile
-# launch for the remaining rows; 7 = eight-phase forced (needs N % 256 == 0 and an even number >= 4 of K-tiles)
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 6, 7])
+# launch for the remaining rows; 7 = eight-phase forced (needs N % 256 == 0 and an even number >= 4 of K-tiles);
+# 9 = 64 x 128 blocks (remainders of a few hundred rows)
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 6, 7, 9])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 64), (300, 256, 128), (4112, 1024, 1024), (33000, 768, 192), (70000, 256, 64),
                                    (33000, 768, 256), (513, 512, 640), (66000, 512, 256), (25096, 2304, 768)])
 def test_variant(dev, variant, M, N, K):
@@ -87,3 +88,34 @@ def test_epilogue_layernorm_partials(dev, M, N, K, act):
     m2 = (parts[..., 1] + 64 * (parts[..., 0] / 64 - mean[:, None]) ** 2).sum(1)
     assert torch.allclose(mean, o.mean(1), rtol=1e-4, atol=1e-5)
     assert torch.allclose(m2 / N, o.var(1, unbiased=False), rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", [7, 9])
+def test_erf_gelu_epilogue_polynomial_against_exact_gelu(dev, variant):
+    """The erf-GELU of the GEMM epilogue is a clamped degree-8 minimax polynomial of Phi (common.h activate2): push EVERY finite
+    bf16 value in [-12, 12] through it (identity weight, so the accumulator is exactly x) and compare with torch's exact fp32 GELU:
+    |error| <= 5e-5 absolute before the bf16 output rounding, i.e. at most one bf16 ulp of the exact result + 5e-5."""
+    from merv_amd import _lib, ops
+    lib = _lib.load()
+    bits = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    vals = bits[torch.isfinite(bits.float()) & (bits.float().abs() <= 12.0)]
+    K = N = 256
+    M = (vals.numel() + K - 1) // K
+    x = torch.zeros(M * K, dtype=torch.bfloat16)
+    x[: vals.numel()] = vals
+    # row m holds K values; out[m][n] = gelu(sum_k a[m][k] I[n][k]) = gelu(a[m][n])
+    a = x.view(M, K).to(dev)
+    w = torch.eye(N, K, dtype=torch.bfloat16, device=dev)
+    lib.merv_debug_set_gemm_variant(variant)
+    try:
+        out = ops.gemm(a, w, act="gelu_erf")
+    finally:
+        lib.merv_debug_set_gemm_variant(0)
+    xf = a.float().cpu()
+    want = F.gelu(xf.double()).float()
+    got = out.float().cpu()
+    ulp = torch.maximum(want.abs() * 2.0**-8, torch.tensor(2.0**-133))  # bf16 spacing at the exact value's magnitude
+    err = (got - want).abs()
+    assert bool((err <= ulp + 5e-5).all()), float((err - ulp).max())
+    assert float(err.max()) < 8e-3 and float(err[xf.abs() < 1.0].max()) < 2.1e-3
+    assert bool((got[xf >= 4.25] == xf[xf >= 4.25]).all()) and bool((got[xf < -4.25] == 0).all())  # saturated exactly (at -4.25 itself Phi = 0.5 - Q(1) = 8e-6)
