@@ -1,8 +1,9 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun). Produces, under gpurun_out/round/:
 #   bench.json            default bench.py line (concurrent encoder streams, roofline leg, parity + cpu baseline, e2e)
-#   kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --sequential` (durations comparable with the
-#                         event-timed roofline leg, which is also sequential)
+#   kernel_stats.csv      rocprofv3 --kernel-trace --stats of `bench.py --sequential --no-prof --steps 6 --warmup 2` (8 identical
+#                         steps; durations comparable with the event-timed roofline legs, which are also sequential)
+#   kernel_roofline.json  tools/kernel_roofline.py: bench.json's roofline.by_kernel joined with that trace
 #   pmc_gemm_traffic.json HBM bytes per GEMM launch from separate FETCH_SIZE / WRITE_SIZE passes (gfx950: FETCH_SIZE x2)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -12,9 +13,10 @@ cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --sequential --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $OUT/trace_bench.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --sequential --steps 6 --warmup 2 --no-prof --no-cpu-baseline --no-e2e > $OUT/trace_bench.json 2> $OUT/trace.err
 cat $OUT/trace_bench.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+python3 $R/tools/kernel_roofline.py $OUT/bench.json $OUT/kernel_stats.csv 8 $OUT/kernel_roofline.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --sequential --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-prof > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --sequential --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-prof > /dev/null 2> $OUT/pmc_write.err
 python3 - $OUT <<'PY'
