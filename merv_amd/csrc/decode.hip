@@ -422,7 +422,13 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
             __hip_atomic_store(ws + 129, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    // publish (every store of this block acknowledged), then take a ticket; the last arrival of this head merges
+    // publish (every store of this block acknowledged), then take a ticket; the last arrival of this head merges.
+    // This is the write-through form of the in-launch hand-off (cdna_hip_programming.md section 5, "Projection GEMM at M = 256"
+    // item 2, "Equally valid": sc1 slab stores -> every wave vmcnt(0) -> __syncthreads -> relaxed agent-scope fetch_add; the
+    // reducer reads the slabs with sc1 loads, EVERY load of them): relaxed agent-scope atomic stores / loads ARE the sc1 forms,
+    // so no release / acquire fence pair is needed and none is paid for (+15 us per layer when tried). Two invariants carry it:
+    // (1) every partial is written and read ONLY through these atomics, (2) one workspace serves one stream -- launches that
+    // share it must not overlap (HipDecoder owns one per decoder and zeroes it in prefill()).
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     unsigned* counter = (unsigned*)(p.ws + (size_t)p.H * p.nsplit * (128 + 2)) + h * 32;  // one 128-byte line per head

@@ -797,7 +797,11 @@ int choose_variant(const GemmArgs& a) {
     // few blocks: at most one 128x128 block per CU, so co-residency cannot hide the DMA latency of a 2-deep ring
     // (a lone block then runs ~1.3 us per K-step); a 4-deep ring keeps three tiles in flight instead
     const long small_tiles = (long)((a.M + 127) / 128) * (a.N / 128);
-    return small_tiles <= num_cus() ? 6 : 1;
+    if (small_tiles <= num_cus()) return 6;
+    // 128-159 tiles of 256 x 128 (what ViViT / SigLIP leave of their N = 768 GEMMs at 16 videos: 6672 rows = 156 tiles): more
+    // 128 x 128 blocks than CUs, and the staggered 256 x 128 kernel on half a round beats two co-resident 128 x 128 blocks
+    // per CU by 2 x (14.1 vs 27.3 us at K = 768, 35.7 vs 86.1 at K = 3072; tools/probes/gemm_remainder.py)
+    return 4;
 }
 
 constexpr long SUBROUND_MIN_TILES = 32;

@@ -375,6 +375,13 @@ class HipDecoder(StaticDecoder):
         self.ws = torch.zeros(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT), dtype=torch.float32, device=self.dev)
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
 
+    def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        # the fused attention launch expects its per-head arrival counters at zero and restores them itself; an aborted launch
+        # (a fault, a killed process sharing the buffer) would leave them non-zero and every later merge would misfire -- so every
+        # generation starts from a zeroed workspace (one memset per generate(), nothing per token)
+        self.ws.zero_()
+        return super().prefill(inputs_embeds)
+
     def _step(self):
         from ._lib import check, ptr
         lib, m = self.lib, self.m
