@@ -367,7 +367,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 for (int i = 0; i < NE; ++i) mx = fmaxf(mx, sa[kb][i]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
-            m_new = fmaxf(m_old, mx);
+            // Deferred max (cdna_hip_programming.md T13): the reference m only has to keep the exponentials in range, not be the
+            // exact running maximum. It moves when this tile's maximum exceeds it by more than thr binary orders (always on the
+            // first tile: m_old = -inf); otherwise the tile is exponentiated against the old reference (values up to 2^thr: fp32
+            // sums and bf16 P keep their relative precision) and the 32-multiply rescale of O below is skipped. With the exact
+            // maximum some query of the wave moved it on nearly every tile (random scores: P(no move) = (1 - 1/t)^32 at tile t),
+            // i.e. ~36 VALU per (query tile, key tile) pair on a VALU-issue-bound kernel.
+            m_new = mx > m_old + p.rescale_thr ? mx : m_old;
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -687,9 +693,15 @@ static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    if (a.nseq <= 0 || a.L <= 0) return hipSuccess;
-    if (a.D != a.heads * HD) return hipErrorInvalidValue;
+hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
+    if (a_in.nseq <= 0 || a_in.L <= 0) return hipSuccess;
+    if (a_in.D != a_in.heads * HD) return hipErrorInvalidValue;
+    AttnArgs a = a_in;
+    {   // deferred-max threshold in binary orders of magnitude; MERV_ATTN_RESCALE_THR=0 gives the exact running maximum (test hook)
+        const char* e = getenv("MERV_ATTN_RESCALE_THR");
+        a.rescale_thr = e ? (float)atof(e) : 8.0f;
+        if (!(a.rescale_thr >= 0.f) || a.rescale_thr > 64.f) a.rescale_thr = 8.0f;
+    }
     ProfScope ps(PROF_ATTN, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
     // block shape. Short sequences: least padded query tiles -- 257- / 261-token sequences are exactly 9 tiles = 3 waves
     // x 3, streamed once per (sequence, head). Long sequences (ViViT, 3137 tokens = 99 tiles): 4 waves x 2 even at 5 %

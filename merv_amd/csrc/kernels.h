@@ -117,6 +117,9 @@ struct AttnArgs {
     bf16_t* out;        // [nseq*L, D]
     int nseq, L, heads, D;
     float scale;        // 1/sqrt(head_dim)
+    // online softmax: the running reference m of a query moves only when a key tile's maximum exceeds it by more than this many
+    // binary orders of magnitude (attention.hip, "deferred max"); set by the launcher (default 8, MERV_ATTN_RESCALE_THR overrides)
+    float rescale_thr;
     // MXFP8 mode: when mx_q is set the output goes out as e4m3 [rows, D] + block scales (layout of mx_quantize)
     // instead of bf16 `out` -- it is the quantised input of the out-projection GEMM
     uint8_t* mx_q;

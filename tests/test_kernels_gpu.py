@@ -270,3 +270,37 @@ def test_fusion_and_splice(dev):
     assert torch.equal(sp, torch.cat([emb[:, :1], out, emb[:, 1:]], 1))
     sp0 = splice(emb, out, 0)
     assert torch.equal(sp0, torch.cat([out, emb], 1))
+
+
+@pytest.mark.parametrize("L,late_key", [(300, 290), (3137, 3000), (261, 250)])
+def test_attention_deferred_max(dev, L, late_key):
+    """The online softmax moves a query's reference only when a key tile's maximum exceeds it by more than 2^thr (attention.hip,
+    deferred max; rule 26 of the guide: force the branch, sweep the threshold). Three queries of head 0 see late keys whose
+    scores jump by (a) less than the threshold -- exponentials > 1 against the kept reference --, (b) just above it, (c) far
+    above it; the shipped threshold, the exact running maximum (thr = 0) and "never but overflow" (thr = 64) must all match
+    the fp32 reference, and each other to rounding."""
+    from merv_amd import ops
+    heads, D = 2, 128
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(L, 3 * D, generator=g) * 0.5
+    # query rows 3, 40, 70 (head 0) all point along +1; late keys of different lengths give score jumps of ~3.5, ~7 and ~40 nats
+    for row in (3, 40, 70):
+        qkv[row, :64] = 1.0
+    qkv[late_key, D:D + 64] = 0.45        # score 0.45 * 64 / 8 = 3.6   (5.2 binary orders: below thr = 8)
+    qkv[late_key + 1, D:D + 64] = 0.9     # 7.2 nats = 10.4 binary orders: above
+    qkv[late_key + 2, D:D + 64] = 5.0     # 40 nats
+    qkv = _bf(qkv).to(dev)
+    ref = _attn_ref(qkv, 1, L, heads)
+    outs = {}
+    try:
+        for thr in ("8", "0", "64"):
+            os.environ["MERV_ATTN_RESCALE_THR"] = thr
+            out = ops.attention(qkv, 1, L, heads)
+            assert torch.isfinite(out.float()).all(), thr
+            assert rel_l2(out, ref) < 1e-2, (thr, L)
+            per_row = ((out.float().cpu() - ref.cpu()).norm(dim=-1) / (ref.cpu().norm(dim=-1) + 1e-20))
+            assert float(per_row.max()) < 3e-2, (thr, L, int(per_row.argmax()))
+            outs[thr] = out.float().cpu()
+    finally:
+        os.environ.pop("MERV_ATTN_RESCALE_THR", None)
+    assert rel_l2(outs["8"], outs["0"]) < 6e-3 and rel_l2(outs["64"], outs["0"]) < 6e-3
