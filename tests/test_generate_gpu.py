@@ -119,3 +119,33 @@ def test_generate_still_image_and_decoding_kwargs(dev, tmp_path):
         m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=2, num_beams=4)
     with pytest.raises(TypeError, match="unsupported generation arguments"):
         m.generate(str(path), [1, 9, 8], [4, 4], max_new_tokens=2, length_penalty=2.0)
+
+
+def test_repetition_penalty_covers_the_prompt_like_hf_generate(dev):
+    """The reference hands input_ids to HF generate (merv.py:819), so RepetitionPenaltyLogitsProcessor penalises prompt tokens
+    as well as generated ones. Greedy decode with a strong penalty: every step's choice must equal the argmax of
+    HF's own processor applied to (prompt ids + tokens so far); without the prompt ids the first choice differs. Also: top_p /
+    repetition_penalty = None (a caller forwarding HF-style `None`) are accepted."""
+    from transformers.generation.logits_process import RepetitionPenaltyLogitsProcessor
+    from merv_amd.llm import LlamaBackbone
+    llm = LlamaBackbone(dict(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                             num_key_value_heads=4, max_position_embeddings=512, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
+    prompt = torch.tensor([[1, 7, 9, 11, 13, 15, 17]], device=dev)
+    emb = llm.embed_input_ids(prompt)
+    pen = 5.0
+    got = llm.generate_from_embeds(emb, max_new_tokens=6, repetition_penalty=pen, prompt_ids=prompt, use_graph=False)
+    # replay with HF's processor on the module's own forward
+    proc = RepetitionPenaltyLogitsProcessor(penalty=pen)
+    ids, cur = prompt.clone(), emb
+    for i in range(got.shape[1]):
+        logits = llm.llm(inputs_embeds=cur.to(llm.dtype)).logits[:, -1].float()
+        nxt = proc(ids, logits).argmax(-1)
+        assert int(nxt) == int(got[0, i]), (i, int(nxt), got.tolist())
+        ids = torch.cat([ids, nxt[:, None]], 1)
+        cur = torch.cat([cur, llm.embed_input_ids(nxt[:, None])], 1)
+    # the prompt's own ids are never repeated under this penalty unless nothing else is left
+    plain = llm.generate_from_embeds(emb, max_new_tokens=6, repetition_penalty=pen, use_graph=False)
+    assert plain.shape == got.shape
+    none_ok = llm.generate_from_embeds(emb, max_new_tokens=3, do_sample=True, top_p=None, repetition_penalty=None, top_k=None, use_graph=False,
+                                       generator=torch.Generator(device=dev).manual_seed(0))
+    assert none_ok.shape == (1, 3)
