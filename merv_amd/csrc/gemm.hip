@@ -27,6 +27,35 @@
 #include <math.h>
 #include <type_traits>
 
+// Diagnostic builds only (tools/probes/gemm_stamps.hip defines MERV_GEMM_STAMPS before including this file): per-wave stamps of
+// the shader clock (s_memtime) and, at entry / exit, of the 100 MHz real-time counter plus the hardware ids of the CU, into a
+// buffer of their own. The product build compiles none of it.
+#ifdef MERV_GEMM_STAMPS
+__device__ unsigned long long* g_gemm_stamps = nullptr;  // [block][8 waves][16]
+#define MERV_GSTAMP_(k, INSTR)                                                                                       \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        unsigned long long t__;                                                                                      \
+        asm volatile(INSTR " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (g_gemm_stamps && (threadIdx.x & 63) == 0)                                                                \
+            g_gemm_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = t__;                         \
+    } while (0)
+#define MERV_GSTAMP(k) MERV_GSTAMP_(k, "s_memtime")
+#define MERV_GSTAMP_REAL(k) MERV_GSTAMP_(k, "s_memrealtime")
+#define MERV_GSTAMP_HWID(k)                                                                                          \
+    do {                                                                                                             \
+        if (g_gemm_stamps && (threadIdx.x & 63) == 0)                                                                \
+            g_gemm_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] =                               \
+                ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32) |    \
+                (unsigned)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));                        \
+    } while (0)
+#else
+#define MERV_GSTAMP(k) do { } while (0)
+#define MERV_GSTAMP_REAL(k) do { } while (0)
+#define MERV_GSTAMP_HWID(k) do { } while (0)
+#endif
+
 namespace merv {
 
 namespace {
@@ -126,6 +155,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
+        if (part == 1) MERV_GSTAMP(8);  // part 0's stores are issued
         uint32_t c_off[EP_IT];  // element offsets (the launcher checks they fit 32 bits)
         bool valid[EP_IT];
         u32x4 resv[EP_IT];
@@ -154,8 +184,10 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
         }
         // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
+        if (part == 0) MERV_GSTAMP(5);  // epilogue operands and part 0's residual rows requested
         if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (part == 0) MERV_GSTAMP(6);  // staging barrier passed
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const float4 cs = cs4[i];
@@ -179,6 +211,8 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
+        if (part == 0) MERV_GSTAMP(7);  // part 0 scaled, activated, packed and staged
+        else MERV_GSTAMP(9);
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
             const int r = (elane >> 3) + 8 * it;
@@ -446,6 +480,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int BKE = ROW_BYTES / ES;           // elements of K per K-tile
     constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MERV_GSTAMP_REAL(0);
+    MERV_GSTAMP_HWID(14);
+    MERV_GSTAMP(1);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -524,8 +561,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     dma_s(0, 0);
     dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
     dma_a(0, 1, 1); dma_b(0, 1, 1);
+    MERV_GSTAMP(2);  // prologue DMAs issued
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    MERV_GSTAMP(3);  // tile 0's early quarters have landed: first phase released
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // trailing group: one barrier behind from here on
 
     typedef int v8i_t __attribute__((ext_vector_type(8)));
@@ -702,8 +741,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #undef MERV_MX_ASM
     if constexpr (MX) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // MFMA results vs. the epilogue's reads
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance the trailing group's extra barrier
+    MERV_GSTAMP(4);  // K-loop done
 
     gemm_epilogue<WTM, WTN, REMAP, ACT, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+    MERV_GSTAMP(10);  // part 1's stores are issued
+#ifdef MERV_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    MERV_GSTAMP(11);  // every store acknowledged
+    MERV_GSTAMP_REAL(12);
 }
 
 // Per-device state: hipFuncSetAttribute and the CU count belong to a device, and one process may drive several
