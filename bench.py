@@ -324,11 +324,57 @@ def main():
         step = step_dp
     elapsed = timed(step)
 
+    def make_line(multi_gpu, roof, parity, cpu, e2e):
+        """The ONE JSON line (rank 0). Also called by the watchdog of the multi-GPU extra legs with what is known by then."""
+        ms_per_step = elapsed / args.steps * 1e3
+        value = G * TOKENS_PER_VIDEO * args.steps / elapsed
+        flops_video = sum(s.flops_per_video() + 2.0 * TOKENS_PER_VIDEO * s.dim * LLM_DIM for s in specs)  # + projectors
+        path_tflops = flops_video * G * args.steps / elapsed / 1e12
+        peak = PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS
+        line = {
+            "metric": "fused visual tokens/s through 4-encoder+projector+fusion (merv-full geometry)",
+            "value": round(value, 1), "unit": "visual-tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "mxfp8 block GEMMs, bf16 elsewhere" if args.mxfp8 else "bf16", "data": "synthetic",
+            "config": {"workload": ("merv-full encoders with MXFP8 block GEMMs (BASELINE.json configs[4] encoder side), "
+                                    "frames [16,16,32,16], 224px" if args.mxfp8 else
+                                    "merv-frozen 4 frozen encoders bf16 inference, frames [16,16,32,16], 224px "
+                                    "(BASELINE.json configs[1])"),
+                       "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
+                       "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if replay is not None else ""),
+                       "layernorm": "separate kernels" if args.no_ln_fold else "LN1 / LN2 folded into qkv / fc1, statistics from the producing GEMM's epilogue",
+                       "parallelism": ("single GPU" if single else
+                                       f"(encoder, video, frame-range) units over {world} GPUs, RCCL {args.exchange} before fusion" if headline_units else
+                                       f"data-parallel over videos on {world} GPUs, no data-path collective"),
+                       "path_tflops": round(path_tflops, 1), "path_frac_of_mfma_peak": round(path_tflops / peak, 4),
+                       "flops_per_video_T": round(flops_video / 1e12, 3),
+                       "e2e_gen_tok_s": e2e["generated_tok_per_s"] if e2e else None,
+                       "multi_gpu": multi_gpu},
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu, "e2e": e2e,
+        }
+        return line
+
     multi_gpu = None
     if multi and not args.no_multi:
         # Extra legs: they must never cost the headline line. Every rank runs the same code on the same plan, so an exception is
         # raised on all ranks alike (no rank is left waiting in a collective); it is reported instead of propagated.
         multi_gpu = {"ranks": world, "videos_per_rank": B}
+        # ... and neither may a collective that never returns (these legs have not run on more than one rank of hardware): a
+        # watchdog on every rank ends the process after MERV_BENCH_LEGS_TIMEOUT seconds (default 300) -- rank 0 prints the headline
+        # line first, with the legs reported as timed out -- instead of leaving the launcher to kill the job without a line.
+        import threading
+
+        def legs_watchdog():
+            msg = f"multi-GPU extra legs did not finish within {legs_timeout:.0f} s (a collective did not return?)"
+            print(f"[bench] rank {rank}: {msg}; exiting with the headline only", file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps(make_line(dict(multi_gpu, error=msg), None, None, None, None)), file=real_stdout, flush=True)
+            os._exit(0)
+
+        legs_timeout = float(os.environ.get("MERV_BENCH_LEGS_TIMEOUT", "300"))
+        watchdog = threading.Timer(legs_timeout, legs_watchdog)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             multi_gpu["dp_tokens_per_s"] = round(G * TOKENS_PER_VIDEO * args.steps / (elapsed if not headline_units else timed(step_dp)), 1)
             for ex in ("all_to_all", "all_gather"):
@@ -358,6 +404,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             multi_gpu["error"] = f"{type(e).__name__}: {e}"
             print(f"[bench] rank {rank}: multi-GPU extra legs failed: {multi_gpu['error']}", file=sys.stderr, flush=True)
+        watchdog.cancel()
         flags = {k: v for k, v in multi_gpu.items() if k.endswith("_bit_equal_to_single_gpu_path")}
         print(f"[bench] rank {rank}/{world}: RCCL ranks {dist.get_world_size()}, placed legs bit-equal to the single-GPU path: {flags}, "
               f"error: {multi_gpu['error']}", file=sys.stderr, flush=True)
@@ -448,33 +495,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = G * TOKENS_PER_VIDEO * args.steps / elapsed
-        flops_video = sum(s.flops_per_video() + 2.0 * TOKENS_PER_VIDEO * s.dim * LLM_DIM for s in specs)  # + projectors
-        path_tflops = flops_video * G * args.steps / elapsed / 1e12
-        peak = PEAK_FP8_TFLOPS if args.mxfp8 else PEAK_BF16_TFLOPS
-        line = {
-            "metric": "fused visual tokens/s through 4-encoder+projector+fusion (merv-full geometry)",
-            "value": round(value, 1), "unit": "visual-tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "mxfp8 block GEMMs, bf16 elsewhere" if args.mxfp8 else "bf16", "data": "synthetic",
-            "config": {"workload": ("merv-full encoders with MXFP8 block GEMMs (BASELINE.json configs[4] encoder side), "
-                                    "frames [16,16,32,16], 224px" if args.mxfp8 else
-                                    "merv-frozen 4 frozen encoders bf16 inference, frames [16,16,32,16], 224px "
-                                    "(BASELINE.json configs[1])"),
-                       "videos_per_gpu_per_step": B, "global_videos_per_step": G, "tokens_per_video": TOKENS_PER_VIDEO,
-                       "encoder_streams": ("sequential" if args.sequential else "concurrent") + (", hipGraph replay" if replay is not None else ""),
-                       "layernorm": "separate kernels" if args.no_ln_fold else "LN1 / LN2 folded into qkv / fc1, statistics from the producing GEMM's epilogue",
-                       "parallelism": ("single GPU" if single else
-                                       f"(encoder, video, frame-range) units over {world} GPUs, RCCL {args.exchange} before fusion" if headline_units else
-                                       f"data-parallel over videos on {world} GPUs, no data-path collective"),
-                       "path_tflops": round(path_tflops, 1), "path_frac_of_mfma_peak": round(path_tflops / peak, 4),
-                       "flops_per_video_T": round(flops_video / 1e12, 3),
-                       "e2e_gen_tok_s": e2e["generated_tok_per_s"] if e2e else None,
-                       "multi_gpu": multi_gpu},
-            "roofline": roof, "parity": parity, "cpu_baseline": cpu, "e2e": e2e,
-        }
-        print(json.dumps(line), file=real_stdout, flush=True)
+        print(json.dumps(make_line(multi_gpu, roof, parity, cpu, e2e)), file=real_stdout, flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
     # The extra placed legs never cost the data-parallel headline its line; but when the unit placement IS the headline
