@@ -63,10 +63,11 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
 }
 
 // ---- GEMV: W [N, K] bf16 row-major streamed once; each wave owns ROWS output rows, lanes stride K in 16-byte chunks ----
-constexpr int GEMV_ROWS = 2;   // rows per wave (x chunk reused across them)
 constexpr int GEMV_WAVES = 4;  // waves per block
 
-template <int NW_MATS, int UN, bool NORM>  // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in
+// NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in; GEMV_ROWS: output rows per wave (the x chunk
+// is reused across them)
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
@@ -461,27 +462,43 @@ hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <int ROWS, int UN>
+static hipError_t launch_gemv_cfg(const DecodeGemvArgs& a, hipStream_t s) {
+    const int rows_per_block = ROWS * GEMV_WAVES;
+    dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
+    const dim3 blk(GEMV_WAVES * 64);
+    if (a.W2) {
+        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, (UN > 4 ? 4 : UN), true, ROWS>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((gemv_kernel<2, (UN > 4 ? 4 : UN), false, ROWS>), grid, blk, 0, s, a);
+    } else if (a.norm_w) {
+        hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS>), grid, blk, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((gemv_kernel<1, UN, false, ROWS>), grid, blk, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     if (a.N <= 0 || a.K <= 0 || a.K % 8 != 0) return hipErrorInvalidValue;
-    const int rows_per_block = GEMV_ROWS * GEMV_WAVES;
     if (a.Nb > 0 || a.Nc > 0) {
-        if (a.W2 || a.res || a.y32 || a.N % GEMV_ROWS || a.Nb % GEMV_ROWS || a.Nc % GEMV_ROWS || (a.Nb > 0 && (!a.Wb || !a.yb)) ||
+        if (a.W2 || a.res || a.y32 || a.N % 2 || a.Nb % 2 || a.Nc % 2 || (a.Nb > 0 && (!a.Wb || !a.yb)) ||
             (a.Nc > 0 && (!a.Wc || !a.yc || a.Nb <= 0)))
             return hipErrorInvalidValue;
     }
-    dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
-    // UN (chunks per lane per trip), step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms, 8: 4.60 ms (284 registers
-    // with the norm arrays live; without them hipcc serialises the 16 loads again: no gain); the norm is a template flag: 3.21 ms
-    const dim3 blk(GEMV_WAVES * 64);
-    if (a.W2) {
-        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, 4, true>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((gemv_kernel<2, 4, false>), grid, blk, 0, s, a);
-    } else if (a.norm_w) {
-        hipLaunchKernelGGL((gemv_kernel<1, 4, true>), grid, blk, 0, s, a);
-    } else {
-        hipLaunchKernelGGL((gemv_kernel<1, 4, false>), grid, blk, 0, s, a);
-    }
-    return hipGetLastError();
+    // UN (chunks per lane per trip) at two rows per wave, step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms,
+    // 8: 4.60 ms (284 registers with the norm arrays live); the norm is a template flag: 3.21 ms.
+    // Rows per wave / unroll for the plain projections (o_proj, down_proj: one matrix, no fused norm, 4096 rows): one row per wave
+    // with the whole 16-byte-chunk batch of a trip doubled (1 x 8) keeps the same 8 loads per lane in flight on twice the waves:
+    // o_proj 7.9 -> 7.8 us, down_proj 20.0 -> 18.6 (tools/probes/decode_kernels.py, MERV_GEMV_CFG sweep). With the RMSNorm fused
+    // in (q / k / v) every wave reduces mean(x^2) itself, so halving the rows per wave doubles that work: 22.1 -> 29.8 us; those
+    // launches and the gate / up pair stay at two rows per wave.
+    static const char* cfg = getenv("MERV_GEMV_CFG");  // tuning hook: "<rows><un>", e.g. "14", "18", "24"
+    const long rows_total = (long)a.N + a.Nb + a.Nc;
+    int rows = (!a.W2 && !a.norm_w && rows_total <= 16384) ? 1 : 2, un = rows == 1 ? 8 : 4;
+    if (cfg && cfg[0] && cfg[1]) { rows = cfg[0] - '0'; un = cfg[1] - '0'; }
+    if (rows == 1 && un == 8) return launch_gemv_cfg<1, 8>(a, s);
+    if (rows == 1) return launch_gemv_cfg<1, 4>(a, s);
+    return launch_gemv_cfg<2, 4>(a, s);
 }
 
 hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s) {
