@@ -45,8 +45,8 @@ PMC_TRAFFIC_FILE = "profiles/r03_pmc_gemm_traffic.json"
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters; 6.29 TB/s is the measured copy rate)
 # kernel-level profiler classes of libmerv_hip.so (include/merv_hip.h, merv_prof_*): (class, name, bound, kernels)
 KERNEL_CLASSES = [
-    (5, "gemm eight-phase, no activation", "mfma", "gemm_bf16_8phase_kernel<false,0,false>: qkv, proj, fc2, temporal qkv / proj, projector"),
-    (6, "gemm eight-phase + activation epilogue", "mfma", "gemm_bf16_8phase_kernel<false,1|2|3,false>: fc1 (GELU + folded-LayerNorm correction)"),
+    (5, "gemm eight-phase, no activation", "mfma", "gemm_bf16_8phase_kernel<false,0,false,EPI>: qkv, proj, fc2, temporal qkv / proj, projector"),
+    (6, "gemm eight-phase + activation epilogue", "mfma", "gemm_bf16_8phase_kernel<false,1|2|3,false,EPI>: fc1 (GELU + folded-LayerNorm correction)"),
     (7, "gemm small tiles", "mfma", "gemm_bf16_kernel<...>: rows the eight-phase launch left over, patch embedding"),
     (8, "attention, K/V resident", "mfma", "attn_kernel<true,4,2,true,true>: LanguageBind 257 / DINOv2 261 tokens"),
     (9, "attention, K/V streamed", "mfma", "attn_kernel<true,4,2,false,false>: ViViT 3137 tokens; SigLIP 196 tokens"),

@@ -56,6 +56,19 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;  // [block][8 waves][16]
 #define MERV_GSTAMP_HWID(k) do { } while (0)
 #endif
 
+// Ablation builds only (tools/probes): MERV_ABL_NOSTORE keeps the whole epilogue but never stores (the condition is a runtime
+// value, so nothing is dead code); MERV_ABL_PLAINSTORE: direct epilogue with L2-allocating stores
+#ifdef MERV_ABL_WRAPROWS  // every output / residual row wraps into the first 4096 rows (8 MB at N = 1024: stays in the L2s)
+#define MERV_ABL_WRAP(r) ((r) & 4095)
+#else
+#define MERV_ABL_WRAP(r) (r)
+#endif
+#ifdef MERV_ABL_NOSTORE
+#define MERV_ABL_STORE_COND &&(p.group_m == 12345)
+#else
+#define MERV_ABL_STORE_COND
+#endif
+
 namespace merv {
 
 namespace {
@@ -86,10 +99,139 @@ MERV_DEVICE float sum8_dpp(float v) {
     return v;
 }
 
-// ---- epilogue (shared by all tile configurations) ----
-template <int WTM_FULL, int WTN, bool REMAP, int ACT, int MSPLIT = 1>
+// ---- epilogue modes (round 4) ----
+// With all eight waves of a block in the epilogue the SIMDs are VALU-throughput-bound (two waves per SIMD: a v_pk_*_f32 or a
+// v_cvt_pk_bf16_f32 retires every ~4.5-4.9 cycles per SIMD, tools/probes/valu_rate.hip), and the generic form spends four packed
+// operations + one conversion per output pair whatever the launch asked for. The launcher therefore picks one of four forms:
+//   EPI_GENERIC  every optional term from its runtime pointer (fold on {1, 0} / colsum 0 when absent, LayerScale 1): MXFP8 kernels and
+//                the combinations the encoder stack never produces
+//   EPI_PLAIN    bias only: the accumulators START at bias[n] (init_acc: the prologue waits for the first DMA anyway), so the
+//                epilogue is activation + conversion -- and needs no operand loads (one L2 round trip less per tile)
+//   EPI_LS       the same, then x LayerScale (DINOv2 proj / fc2)
+//   EPI_FOLD     folded LayerNorm: fma(acc, rstd, fma(-mean rstd, colsum, bias)) -- two packed operations instead of three
+// Every tile configuration uses the same form for the same launch, so a row gives the same bits whichever kernel computes it.
+enum : int { EPI_GENERIC = 0, EPI_PLAIN = 1, EPI_LS = 2, EPI_FOLD = 3 };
+
+// column of accumulator fragment i, register r, lane group fq, relative to the wave tile's first column
+template <bool DIRECT>
+MERV_DEVICE int frag_col(int i, int fq) { return DIRECT ? 32 * (i >> 1) + 8 * fq + 4 * (i & 1) : 16 * i + 4 * fq; }
+
+// EPI_PLAIN / EPI_LS: the accumulators start at the bias. The wave tile's 64 bias values are wave-uniform addresses, so they come
+// by SCALAR loads (their own counter: nothing here touches the vmcnt queue the prologue's LDS-DMAs are counted on -- a vector load
+// would make hipcc drain that queue at its first use, and an asm load's destination registers are copied by hipcc before the data
+// lands) and each lane picks its lane group's four columns per fragment. wn0 must be provably wave-uniform at the call site.
+template <int EPI, bool DIRECT, int MI>
+MERV_DEVICE void acc_init(const GemmArgs& p, f32x4 (&acc)[4][MI], int lane, int wn0) {
+    if constexpr (EPI == EPI_PLAIN || EPI == EPI_LS) {
+        if (p.bias) {
+            // constant address space (read-only for the whole launch): s_load_dwordx16 whatever stores / DMAs precede
+            typedef __attribute__((address_space(4))) const f32x16 cblock_t;
+            const int fq = lane >> 4;
+            auto pick = [&](float b0, float b1, float b2, float b3) { return fq == 0 ? b0 : fq == 1 ? b1 : fq == 2 ? b2 : b3; };
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {  // 32-column halves of the wave tile: two 16-float blocks each
+                const f32x16 B0 = *(cblock_t*)(p.bias + wn0 + 32 * h), B1 = *(cblock_t*)(p.bias + wn0 + 32 * h + 16);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (DIRECT)  // fragment 2 h + e, lane group fq: column 32 h + 8 fq + 4 e + r
+                            v[r] = pick(B0[4 * e + r], B0[8 + 4 * e + r], B1[4 * e + r], B1[8 + 4 * e + r]);
+                        else                   // fragment 2 h + e: column 16 (2 h + e) + 4 fq + r
+                            v[r] = e == 0 ? pick(B0[r], B0[4 + r], B0[8 + r], B0[12 + r]) : pick(B1[r], B1[4 + r], B1[8 + r], B1[12 + r]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) acc[2 * h + e][j] = v;
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// per-column operands of the epilogue for this lane (index i = accumulator fragment), by mode
+template <int EPI, bool DIRECT>
+struct EpiCols {
+    float4 bias[4], ls[4], cs[4];
+    MERV_DEVICE void load(const GemmArgs& p, int wn0, int fq) {
+        if constexpr (EPI == EPI_GENERIC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = wn0 + frag_col<DIRECT>(i, fq);
+                bias[i] = p.bias ? *(const float4*)(p.bias + c) : float4{0.f, 0.f, 0.f, 0.f};
+                ls[i] = p.lscale ? *(const float4*)(p.lscale + c) : float4{1.f, 1.f, 1.f, 1.f};
+                cs[i] = p.row_stats ? *(const float4*)(p.ln_colsum + c) : float4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else if constexpr (EPI == EPI_LS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ls[i] = *(const float4*)(p.lscale + wn0 + frag_col<DIRECT>(i, fq));
+        } else if constexpr (EPI == EPI_FOLD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = wn0 + frag_col<DIRECT>(i, fq);
+                bias[i] = p.bias ? *(const float4*)(p.bias + c) : float4{0.f, 0.f, 0.f, 0.f};
+                cs[i] = *(const float4*)(p.ln_colsum + c);
+            }
+        }
+    }
+};
+// one accumulator quad -> its two finished pairs (fp32, before the bf16 conversion)
+template <int EPI, int ACT, bool DIRECT>
+MERV_DEVICE void epi_quad(const f32x4 v, const EpiCols<EPI, DIRECT>& c, int i, const float2 rs, f32x2& lo, f32x2& hi) {
+    if constexpr (EPI == EPI_GENERIC) {
+        // fma(acc, rstd, (-mean rstd) * colsum) + bias: the roundings of rounds 1-3 ({1, 0} / colsum 0 without a fold: acc exactly)
+        const f32x2 rx = {rs.x, rs.x};
+        lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, rx, f32x2{c.cs[i].x, c.cs[i].y} * rs.y) + f32x2{c.bias[i].x, c.bias[i].y};
+        hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, rx, f32x2{c.cs[i].z, c.cs[i].w} * rs.y) + f32x2{c.bias[i].z, c.bias[i].w};
+    } else if constexpr (EPI == EPI_FOLD) {
+        const f32x2 rx = {rs.x, rs.x}, ry = {rs.y, rs.y};
+        lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, rx,
+                                       __builtin_elementwise_fma(f32x2{c.cs[i].x, c.cs[i].y}, ry, f32x2{c.bias[i].x, c.bias[i].y}));
+        hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, rx,
+                                       __builtin_elementwise_fma(f32x2{c.cs[i].z, c.cs[i].w}, ry, f32x2{c.bias[i].z, c.bias[i].w}));
+    } else {  // the bias is already in the accumulator
+        lo = f32x2{v[0], v[1]};
+        hi = f32x2{v[2], v[3]};
+    }
+    activate4<ACT>(lo, hi);
+    if constexpr (EPI == EPI_GENERIC || EPI == EPI_LS) {
+        lo = lo * f32x2{c.ls[i].x, c.ls[i].y};
+        hi = hi * f32x2{c.ls[i].z, c.ls[i].w};
+    }
+}
+template <int EPI>
+constexpr bool epi_needs_row_stats = (EPI == EPI_GENERIC || EPI == EPI_FOLD);
+
+// ---- epilogue through LDS (shared by all tile configurations) ----
+// Eight-phase kernel: every wave owns sixteen 1-KiB LDS slots, the destinations of its own DMA pieces (8 per buffer). In the LAST
+// K-tile they are dead one after the other -- buffer 0 from its first phase, the early quarters of buffer 1 from phases 3 / 4 -- and
+// the residual rows of the wave's output tile (16 pieces of 8 rows x 128 B, lane-linear: exactly what the epilogue's read-back
+// lane wants) are brought there by LDS-DMA under the last MFMAs (pieces 0-11; 12-15 as register loads at the top of the epilogue).
+MERV_DEVICE int own_slot_a(int buf, int u, int sq, int wave) { return buf * 65536 + (u * 16 + sq * 8 + wave) * 1024; }
+MERV_DEVICE int own_slot_b(int buf, int u, int sq, int wave) {
+    return buf * 65536 + 32768 + (((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3)) * 1024;
+}
+MERV_DEVICE int res_slot(int q, int wave) {  // q = 0 .. 11, compile-time at every call site
+    if (q < 4) return own_slot_a(0, q >> 1, q & 1, wave);
+    if (q < 8) return own_slot_b(0, (q - 4) >> 1, (q - 4) & 1, wave);
+    if (q < 10) return own_slot_a(1, q - 8, 0, wave);
+    return own_slot_b(1, q - 10, 0, wave);
+}
+constexpr int RES_LDS_PIECES = 12;
+constexpr int SPARE_LDS_BASE = 131072;  // the 32 KB above the two operand buffers (160 KB blocks)
+
+// SPARE (eight-phase bf16 kernels, MSPLIT = 4): the transpose is staged in the 32 KB of LDS above the operand buffers (4 KB per
+// wave, 32 rows per part), a region the K-loop never touches -- no block barrier between the last MFMA and the first store -- and
+// the residual rows come from the wave's own LDS slots (above) instead of global memory.
+template <int WTM_FULL, int WTN, bool REMAP, int ACT, int EPI, int MSPLIT = 1, bool SPARE = false>
 MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FULL / 16], char* smem, int wave, int lane, int m0,
                                int n0, int wr, int wc) {
+    static_assert(!SPARE || (WTM_FULL == 128 && MSPLIT == 4 && !REMAP), "spare-region staging: 128-row wave tiles in four parts");
     // MSPLIT > 1: the wave's rows are finished in MSPLIT passes of WTM rows each (bounds the registers the residual
     // rows and offsets take next to a 128-register accumulator)
     constexpr int WTM = WTM_FULL / MSPLIT;
@@ -109,50 +251,41 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     int elane = lane;
     asm volatile("" : "+v"(elane));
     const int ec = elane & 7;  // this lane's 16-byte chunk (8 columns) of each row it handles
-    float4 bias4[NI], ls4[NI];
-    if (p.bias) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bias4[i] = *(const float4*)(p.bias + wn0 + i * 16 + fq * 4);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) bias4[i] = float4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (p.lscale) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) ls4[i] = *(const float4*)(p.lscale + wn0 + i * 16 + fq * 4);
-    } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) ls4[i] = float4{1.f, 1.f, 1.f, 1.f};
-    }
-    // folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]. Row statistics (the row of acc[i][j] is j * 16 + frow of its
-    // part) and column sums are requested HERE, ahead of the staging barrier and the residual loads, so their latency is hidden
-    // (loaded at first use they stalled every part of every tile for a full global-load round trip: +3 % on qkv / fc1 launches)
-    // Without a fold the same arithmetic runs on {rstd, -mean rstd} = {1, 0} and colsum = 0 -- acc * 1 + 0 * 0 is acc exactly -- so
-    // the loop below has no per-element select on the (runtime, wave-uniform) pointer: hipcc turned `if (p.row_stats)` around the
-    // fma into two v_cndmask per pair on top of both candidates.
+    // Per-column operands and (folded LayerNorm: v = acc * rstd + (-mean * rstd) * colsum[n]) per-row statistics are requested HERE,
+    // ahead of the staging barrier and the residual loads, so their latency is hidden (loaded at first use they stalled every part
+    // of every tile for a full global-load round trip: +3 % on qkv / fc1 launches). The row of acc[i][j] is j * 16 + frow of its part.
+    EpiCols<EPI, false> cols;
+    cols.load(p, wn0, elane >> 4);
     float2 rs_all[MSPLIT][MI];
-    float4 cs4[NI];
-    if (p.row_stats) {
-        const int efrow = elane & 15;
 #pragma unroll
-        for (int part = 0; part < MSPLIT; ++part)
+    for (int part = 0; part < MSPLIT; ++part)
 #pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + efrow;
-                m = m < p.M ? m : p.M - 1;
-                rs_all[part][j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
-            }
+        for (int j = 0; j < MI; ++j) rs_all[part][j] = float2{1.f, 0.f};
+    if constexpr (epi_needs_row_stats<EPI>) {
+        if (EPI == EPI_FOLD || p.row_stats) {
+            const int efrow = elane & 15;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) cs4[i] = *(const float4*)(p.ln_colsum + wn0 + i * 16 + (elane >> 4) * 4);
-    } else {
+            for (int part = 0; part < MSPLIT; ++part)
 #pragma unroll
-        for (int part = 0; part < MSPLIT; ++part)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) rs_all[part][j] = float2{1.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NI; ++i) cs4[i] = float4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < MI; ++j) {
+                    int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + efrow;
+                    m = m < p.M ? m : p.M - 1;
+                    rs_all[part][j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
+                }
+        }
     }
-    char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
+    char* stg = smem + (SPARE ? SPARE_LDS_BASE : 0) + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
+    u32x4 res_tail[4];  // SPARE: residual pieces 12-15 (the last part's rows), requested now
+    if constexpr (SPARE) {
+        if (p.res) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int m = m0 + wr * WTM_FULL + (RES_LDS_PIECES + it) * 8 + (elane >> 3);
+                m = m < p.M ? m : p.M - 1;
+                res_tail[it] = *(const u32x4*)(p.res + (size_t)((uint32_t)m * (uint32_t)p.ldres) + wn0 + ec * 8);
+            }
+        }
+    }
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
         if (part == 1) MERV_GSTAMP(8);  // part 0's stores are issued
@@ -171,37 +304,32 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
                 if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
             }
-            c_off[it] = (uint32_t)orow * (uint32_t)p.ldc + wn0 + ec * 8;
-            r_off[it] = (uint32_t)rr * (uint32_t)p.ldres + wn0 + ec * 8;
+            c_off[it] = (uint32_t)MERV_ABL_WRAP(orow) * (uint32_t)p.ldc + wn0 + ec * 8;
+            r_off[it] = (uint32_t)MERV_ABL_WRAP(rr) * (uint32_t)p.ldres + wn0 + ec * 8;
         }
         // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
         // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
-        if (p.res) {
+        if constexpr (!SPARE) {
+            if (p.res) {
 #pragma unroll
-            for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
-        } else {
+                for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
+            } else {
 #pragma unroll
-            for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
+                for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
+            }
         }
-        // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
+        // part 0: every wave is done with the stage ring (SPARE: the staging region is not part of it); later parts: this wave's
+        // reads of its staging region returned
         if (part == 0) MERV_GSTAMP(5);  // epilogue operands and part 0's residual rows requested
-        if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (part == 0 && !SPARE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (part == 0) MERV_GSTAMP(6);  // staging barrier passed
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const float4 cs = cs4[i];
 #pragma unroll
             for (int j = 0; j < MI; ++j) {
-                const f32x4 v = acc[i][part * MI + j];
-                const float2 rs = rs_all[part][j];
-                // fma(acc, rstd, (-mean rstd) * colsum) + bias: the same roundings as the scalar form of rounds 1-2
-                const f32x2 rx = {rs.x, rs.x};
-                f32x2 lo = __builtin_elementwise_fma(f32x2{v[0], v[1]}, rx, f32x2{cs.x, cs.y} * rs.y) + f32x2{bias4[i].x, bias4[i].y};
-                f32x2 hi = __builtin_elementwise_fma(f32x2{v[2], v[3]}, rx, f32x2{cs.z, cs.w} * rs.y) + f32x2{bias4[i].z, bias4[i].w};
-                activate4<ACT>(lo, hi);
-                lo = lo * f32x2{ls4[i].x, ls4[i].y};
-                hi = hi * f32x2{ls4[i].z, ls4[i].w};
+                f32x2 lo, hi;
+                epi_quad<EPI, ACT, false>(acc[i][part * MI + j], cols, i, rs_all[part][j], lo, hi);
                 u32x2 o;
                 o[0] = pack2bf(lo[0], lo[1]);
                 o[1] = pack2bf(hi[0], hi[1]);
@@ -213,11 +341,31 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
         if (part == 0) MERV_GSTAMP(7);  // part 0 scaled, activated, packed and staged
         else MERV_GSTAMP(9);
+        if constexpr (SPARE) {
+            if (p.res) {
+                // the DMA pieces were issued by THIS wave into its own slots: its own vmcnt orders them for its own reads
+                if (part == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < EP_IT; ++it) {
+                    const int q = part * EP_IT + it;
+                    if (q < RES_LDS_PIECES) resv[it] = *(const u32x4*)(smem + res_slot(q < RES_LDS_PIECES ? q : 0, wave) + elane * 16);
+                    else resv[it] = res_tail[q >= RES_LDS_PIECES ? q - RES_LDS_PIECES : 0];
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        float2 row_part = float2{0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
             const int r = (elane >> 3) + 8 * it;
             u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
+#ifdef MERV_ABL_RESNOUSE  // ablation: the residual rows are loaded but only consumed after the part's stores were issued
+            if (false) {
+#else
             if (p.res) {
+#endif
                 // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -233,9 +381,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { const float d = f[q] - mu; m2 = fmaf(d, d, m2); }
                 m2 = sum8_dpp(m2);
-                const int m = m0 + wr * WTM_FULL + part * WTM + (elane >> 3) + 8 * it;
-                if (valid[it] && ec == 0)
-                    *(float2*)(p.stats_out + 2 * ((size_t)m * (p.N >> 6) + (wn0 >> 6))) = float2{sm, m2};
+                if (ec == it) row_part = float2{sm, m2};  // lane 8 g + it keeps row g + 8 it of this part
             }
             if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (4 lanes = one 32-column block of the row)
                 float r[8];
@@ -249,14 +395,212 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                     *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
                     if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
                 }
-            } else if (valid[it]) {
+            } else if (valid[it] MERV_ABL_STORE_COND) {
                 // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
                 // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
+#ifdef MERV_ABL_PLAINSTORE
+                *(u32x4*)(p.C + (size_t)c_off[it]) = t;
+#else
                 __builtin_nontemporal_store(t, (u32x4*)(p.C + (size_t)c_off[it]));
+#endif
             }
         }
+        if (p.stats_out) {
+            // lane l holds row (l >> 3) + 8 (l & 7): transpose the 8 x 8 lane grid so that lane L holds row L, and the part's
+            // partials go out as ONE store of 8 * EP_IT consecutive float2 (layout [N / 64][M][2]: rows contiguous per column tile)
+            const int src = 8 * (elane & 7) + (elane >> 3);
+            const float sm = __shfl(row_part.x, src, 64), m2 = __shfl(row_part.y, src, 64);
+            const int m = m0 + wr * WTM_FULL + part * WTM + elane;
+            if (elane < 8 * EP_IT && m < p.M)
+                *(float2*)(p.stats_out + 2 * ((size_t)(wn0 >> 6) * p.stats_ld + m)) = float2{sm, m2};
+        }
+#ifdef MERV_ABL_RESNOUSE
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) asm volatile("" ::"v"(resv[it]));
+#endif
     }
 }
+
+// ---- direct epilogue (round 4): no LDS transpose, no staging barrier ----
+// W rows are PERMUTED at the DMA source (w_row_perm32 below): inside every 32-row group of the block's W tile, LDS row slot
+// 16 e + 4 g + r holds W row 8 g + 4 e + r. The LDS image, the ds_read_b128 addresses and the bank pattern are what they were
+// (the source swizzle uses the slot), but the D^T fragments now pair up: MFMA i = 2 nh + e of a wave leaves in lane (frow, g),
+// register r, column 32 nh + 8 g + 4 e + r of row frow -- so acc[2 nh][j] and acc[2 nh + 1][j] together are 8 CONSECUTIVE
+// columns = one 16-byte bf16 chunk, and the four lane groups g of a row cover a 64-byte row segment. Residual rows are loaded
+// and results stored straight from / to registers, 16 B per lane, 16 rows x 64 B per instruction; nothing crosses LDS and the
+// waves of a block no longer meet at a barrier between their last MFMA and their last store.
+MERV_DEVICE int w_row_perm32(int slot) {  // slot = 16 e + 4 g + r  ->  W row 8 g + 4 e + r (within a 32-row group)
+    return (slot & ~31) + 8 * ((slot >> 2) & 3) + 4 * ((slot >> 4) & 1) + (slot & 3);
+}
+// butterfly over the four 16-lane rows of the wave (lanes l, l ^ 16, l ^ 32, l ^ 48): VALU only
+MERV_DEVICE float sum_rows4(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+MERV_DEVICE float max_rows4(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+template <int WTM_FULL, bool REMAP, int ACT, int EPI, int MSPLIT = 1>
+MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FULL / 16], int lane, int m0, int n0, int wr, int wc) {
+    constexpr int WTM = WTM_FULL / MSPLIT;
+    constexpr int MI = WTM / 16;
+    // opaque copy of the lane id: keeps the epilogue's index arithmetic below the K-loop (see gemm_epilogue)
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int frow = elane & 15, fq = elane >> 4;
+    const int wn0 = n0 + wc * 64;
+    const int nl = wn0 + 8 * fq;  // this lane's chunk of the 32-column half nh: columns nl + 32 nh .. + 7
+    // per-column operands, index i = 2 nh + e like the accumulators (columns nl + 32 nh + 4 e .. + 3), and the folded LayerNorm's rows
+    EpiCols<EPI, true> cols;
+    cols.load(p, wn0, fq);
+    float2 rs_all[MSPLIT][MI];
+#pragma unroll
+    for (int part = 0; part < MSPLIT; ++part)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) rs_all[part][j] = float2{1.f, 0.f};
+    if constexpr (epi_needs_row_stats<EPI>) {
+        if (EPI == EPI_FOLD || p.row_stats) {
+#pragma unroll
+            for (int part = 0; part < MSPLIT; ++part)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
+                    m = m < p.M ? m : p.M - 1;
+                    rs_all[part][j] = *(const float2*)(p.row_stats + 2 * (size_t)m);
+                }
+        }
+    }
+#pragma unroll
+    for (int part = 0; part < MSPLIT; ++part) {
+        if (part == 1) MERV_GSTAMP(8);
+        uint32_t c_off[MI], r_off[MI];  // element offsets of this lane's nh = 0 chunk (the launcher checks they fit 32 bits)
+        bool valid[MI];
+        u32x4 resv[MI][2];
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            const int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
+            valid[j] = m < p.M;
+            const int mc = valid[j] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
+            int orow = mc, rr = mc;
+            if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
+                if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
+                if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
+            }
+            c_off[j] = (uint32_t)MERV_ABL_WRAP(orow) * (uint32_t)p.ldc + nl;
+            r_off[j] = (uint32_t)MERV_ABL_WRAP(rr) * (uint32_t)p.ldres + nl;
+        }
+        // one wave-uniform branch around ALL residual loads
+        if (p.res) {
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) resv[j][nh] = *(const u32x4*)(p.res + (size_t)r_off[j] + 32 * nh);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) resv[j][nh] = u32x4{0u, 0u, 0u, 0u};
+        }
+        if (part == 0) MERV_GSTAMP(5);
+        if (part == 0) MERV_GSTAMP(6);
+        static_assert(MI <= 4, "one lane group per 16-row fragment keeps its LayerNorm partials");
+        float2 row_part = float2{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+            u32x4 t[2];
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = 2 * nh + e;
+                    f32x2 lo, hi;
+                    epi_quad<EPI, ACT, true>(acc[i][part * MI + j], cols, i, rs_all[part][j], lo, hi);
+                    t[nh][2 * e] = pack2bf(lo[0], lo[1]);
+                    t[nh][2 * e + 1] = pack2bf(hi[0], hi[1]);
+                }
+                if (p.res) {
+                    // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        t[nh][q] = pack2bf(bflo(t[nh][q]) + bflo(resv[j][nh][q]), bfhi(t[nh][q]) + bfhi(resv[j][nh][q]));
+                }
+            }
+            const int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
+            if (p.stats_out) {  // uniform: {sum, M2} of this row's 64 columns: 16 values here, the other 48 in lanes l ^ 16, ^ 32, ^ 48
+                float f[16];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { f[2 * q] = bflo(t[q >> 2][q & 3]); f[2 * q + 1] = bfhi(t[q >> 2][q & 3]); }
+                const float s8a = ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+                const float s8b = ((f[8] + f[9]) + (f[10] + f[11])) + ((f[12] + f[13]) + (f[14] + f[15]));
+                const float sm = sum_rows4(s8a + s8b);
+                const float mu = sm * (1.f / 64.f);
+                float m2a = 0.f, m2b = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float da = f[q] - mu, db = f[8 + q] - mu;
+                    m2a = fmaf(da, da, m2a);
+                    m2b = fmaf(db, db, m2b);
+                }
+                const float m2 = sum_rows4(m2a + m2b);
+                if (fq == j) row_part = float2{sm, m2};  // lane 16 j + frow keeps row 16 j + frow of this part
+            }
+            if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (the four lanes of a row = one 32-column block per nh)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    float r[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { r[2 * q] = bflo(t[nh][q]); r[2 * q + 1] = bfhi(t[nh][q]); }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) amax = fmaxf(amax, fabsf(r[q]));
+                    amax = max_rows4(amax);
+                    const int ex = mx_shared_exponent(amax);
+                    const float inv = __uint_as_float((uint32_t)(127 - ex) << 23);
+                    const u32x2 q8 = u32x2{mx_pack4(r[0], r[1], r[2], r[3], inv), mx_pack4(r[4], r[5], r[6], r[7], inv)};
+                    const int col = nl + 32 * nh;
+                    if (valid[j]) {
+                        *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
+                        if (fq == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)(ex + 127);
+                    }
+                }
+            } else if (valid[j] MERV_ABL_STORE_COND) {
+                // streaming stores (no L2 allocation: see gemm_epilogue)
+#ifdef MERV_ABL_PLAINSTORE
+                *(u32x4*)(p.C + (size_t)c_off[j]) = t[0];
+                *(u32x4*)(p.C + (size_t)c_off[j] + 32) = t[1];
+#else
+                __builtin_nontemporal_store(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
+                __builtin_nontemporal_store(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
+#endif
+            }
+        }
+        if (p.stats_out) {  // one store of 16 MI consecutive float2 per part (layout [N / 64][M][2])
+            const int m = m0 + wr * WTM_FULL + part * WTM + elane;
+            if (elane < 16 * MI && m < p.M)
+                *(float2*)(p.stats_out + 2 * ((size_t)(wn0 >> 6) * p.stats_ld + m)) = row_part;
+        }
+        if (part == 0) MERV_GSTAMP(7);
+        else MERV_GSTAMP(9);
+    }
+}
+
+// Which epilogue a launch takes (tools/gemm_ksweep.py, tools/gemm_bench.py, same-box pairs, EXPERIMENTS section 1): the direct form wins
+// where the epilogue is VALU-heavy (activation launches: fc1 -3 %), ties with a residual, and loses 1.5 us per tile on plain
+// launches (half-line streaming stores). A/B builds: -DMERV_GEMM_EPILOGUE=0 (always through LDS) / 1 (always direct).
+#ifndef MERV_GEMM_EPILOGUE
+#define MERV_GEMM_EPILOGUE 2
+#endif
+#ifndef MERV_GEMM_SPARE  // A/B builds: -DMERV_GEMM_SPARE=0 = staging inside the stage ring behind a block barrier, residual rows by register loads
+#define MERV_GEMM_SPARE 1
+#endif
+template <int ACT>
+constexpr bool gemm_direct_epilogue = (MERV_GEMM_EPILOGUE == 1) || (MERV_GEMM_EPILOGUE == 2 && ACT != ACT_NONE);
 
 template <int N>
 MERV_DEVICE void wait_dma_barrier() {
@@ -269,8 +613,9 @@ MERV_DEVICE void wait_dma_barrier() {
 //   wait(my DMA of tile kt) ; barrier  => tile kt is complete in LDS AND every wave has finished reading tile kt-1
 //   issue DMA of tile kt+NSTAGE-1 into the stage tile kt-1 occupied, one 1-KiB piece after each row of MFMAs
 //   (a DMA piece costs ~60-180 issue cycles: spread out, the SIMD's other wave fills the gap with its MFMAs)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER, bool REMAP, int ACT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmArgs p) {
+    constexpr bool DIRECT = gemm_direct_epilogue<ACT>;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // per-wave output tile
     constexpr int MI = WTM / 16, NI = WTN / 16;
@@ -314,8 +659,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
     }
 #pragma unroll
     for (int i = 0; i < W_PIECES; ++i) {
-        const int row = (i * NW + wave) * 8 + (lane >> 3);
-        w_src[i] = p.W + (size_t)(n0 + row) * p.ldw + (((lane & 7) ^ (row & 7)) * 8);
+        const int row = (i * NW + wave) * 8 + (lane >> 3);  // LDS row slot (the swizzle follows the slot)
+        const int wrow = DIRECT ? w_row_perm32(row) : row;  // W row it receives (gemm_epilogue_direct)
+        w_src[i] = p.W + (size_t)(n0 + wrow) * p.ldw + (((lane & 7) ^ (row & 7)) * 8);
     }
     // piece `pc` (0..DPS-1) of tile kt into stage `buf`
     auto dma_piece = [&](int kt, int buf, int pc) {
@@ -326,11 +672,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
 
+    static_assert(NI == 4, "64-column wave tiles");
     f32x4 acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = p.K / BK;
     // per-lane fragment addressing: row = l & 15 inside each 16-row fragment, 16-byte chunk (l >> 4) + 4*kk
@@ -344,6 +687,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
 #pragma unroll
             for (int pc = 0; pc < DPS; ++pc) dma_piece(s0, s0, pc);
         }
+    // the accumulators start at the bias (EPI_PLAIN / EPI_LS) while the first tiles are in flight
+    acc_init<EPI, DIRECT>(p, acc, lane, n0 + wc * WTN);
 
     // fragments of one K=32 half of stage `buf`
     auto read_half = [&](int buf, int kk, bf16x8(&af)[MI], bf16x8(&wf)[NI]) {
@@ -442,7 +787,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
         mma_half(haf, hwf, 0, 0, 0, std::false_type{});
     }
 
-    gemm_epilogue<WTM, WTN, REMAP, ACT>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+    if constexpr (DIRECT) {
+        static_assert(WTN == 64, "the direct epilogue pairs the four 16-column fragments of a 64-column wave tile");
+        gemm_epilogue_direct<WTM, REMAP, ACT, EPI>(p, acc, lane, m0, n0, wr, wc);
+    } else {
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -466,7 +816,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
 // time the trailing wave group has executed the same wait (rule "read a staged buffer one phase AFTER the wait that
 // retires it", one barrier more because of the stagger).
 // ---------------------------------------------------------------------------------------------------------
-template <bool REMAP, int ACT, bool MX>
+template <bool REMAP, int ACT, bool MX, int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // MX = true: the same schedule on MXFP8 operands (OCP e4m3 elements, one E8M0 scale per 32 elements of K,
     // v_mfma_scale_f32_16x16x128_f8f6f4: twice the bf16 MFMA rate and half the operand bytes). A K-tile is still 128
@@ -479,6 +829,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int ES = MX ? 1 : 2;                // bytes per operand element
     constexpr int BKE = ROW_BYTES / ES;           // elements of K per K-tile
     constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
+    constexpr bool DIRECT = gemm_direct_epilogue<ACT> && !MX;  // MX: the W block scales are laid out by (unpermuted) row fragment
+    static_assert(!MX || EPI == EPI_GENERIC, "MXFP8 launches take the generic epilogue");
+    constexpr bool SPARE = MERV_GEMM_SPARE && !MX && !DIRECT && !REMAP;  // 160 KB blocks: epilogue staged above the buffers, residual rows by LDS-DMA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MERV_GSTAMP_REAL(0);
     MERV_GSTAMP_HWID(14);
@@ -509,7 +862,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
             int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
             grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
             a_src[sq][u] = (const char*)p.A + (size_t)grow * p.lda * ES + sw8;
-            const int nrow = n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (wave & 3) * 8 + r8;
+            // LDS row slot ((wave >> 2) + 2 u) * 64 + sq * 32 + (wave & 3) * 8 + r8; DIRECT: it receives the permuted W row
+            const int s32 = (wave & 3) * 8 + r8;
+            const int nrow = n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32);
             b_src[sq][u] = (const char*)p.W + (size_t)nrow * p.ldw * ES + sw8;
         }
     auto dma = [&](const char* src, int lds_off) {
@@ -521,6 +876,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
+#ifdef MERV_ABL_HALFDMA  // ablation: W tiles after K-tile 0 are never loaded (garbage results; is the K-loop load-path-bound?)
+        if (t > 0) return;
+#endif
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             dma(b_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
@@ -544,10 +902,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     };
 
     f32x4 acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = p.K / BKE;
     const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
@@ -561,6 +915,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     dma_s(0, 0);
     dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
     dma_a(0, 1, 1); dma_b(0, 1, 1);
+    acc_init<EPI, DIRECT>(p, acc, lane, n0 + wc * WTN);  // EPI_PLAIN / EPI_LS: the accumulators start at the bias (scalar loads)
     MERV_GSTAMP(2);  // prologue DMAs issued
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -686,18 +1041,40 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // phase 2 and its A-late quarter in phase 3, so phases 1 and 2 each retire one of them before their first barrier (the
     // wave's queue then holds, youngest last: [the quarter wanted][the other late quarter or nothing][tile 1: A-early, B-early,
     // (MX scales), B-late, (A-late)] -> all but the 8 (MX: 9) youngest), one phase ahead of the read as the ordering rule asks.
+    // SPARE, last K-tile only: residual piece q of this wave's output tile (rows 8 q .. 8 q + 7) into the wave's own dead slot
+    const bool res_dma = SPARE && p.res != nullptr;
+    auto res_pieces = [&](auto q0_tag, auto n_tag) {
+        if constexpr (SPARE) {
+            if (res_dma) {
+                constexpr int q0 = decltype(q0_tag)::value, n = decltype(n_tag)::value;
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));  // keep the address arithmetic here (not hoisted over the K-loop)
+#pragma unroll
+                for (int q = q0; q < q0 + n; ++q) {
+                    int row = m0 + wr * WTM + q * 8 + (l2 >> 3);
+                    row = row < p.M ? row : p.M - 1;
+                    const bf16_t* src = p.res + (size_t)((uint32_t)row * (uint32_t)p.ldres) + (n0 + wc * WTN) + (l2 & 7) * 8;
+                    dma((const char*)src, res_slot(q, wave));
+                }
+            }
+        }
+    };
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
     auto k_tile = [&](int t, auto buf_tag, auto mode_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
         static_assert(!FIRST || MODE == 0, "the first tile always has two successors");
+        static_assert(MODE != 2 || BUF == 1, "the last tile lives in buffer 1 (res_slot assumes buffer 0 is dead)");
         // phase 1
         read_scales(BUF);
         read_w(BUF, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(BUF, 0);
         if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
+        if constexpr (MODE == 2) res_pieces(I0{}, I4{});  // buffer 0 is dead: pieces 0-3 -> this wave's A slots there
         if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I0{});
@@ -705,6 +1082,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         // phase 2
         read_w(BUF, 1);
         if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
+        if constexpr (MODE == 2) res_pieces(I4{}, I4{});  // pieces 4-7 -> its B slots of buffer 0
         if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I1{});
@@ -712,10 +1090,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         // phase 3
         read_a(BUF, 1);
         if constexpr (has2) dma_a(0, t + 2, BUF);
+        if constexpr (MODE == 2) res_pieces(std::integral_constant<int, 8>{}, I2{});  // where tile t + 2's A-early quarter would go
         MERV_PH_LOADED();
         quadrant(I1{}, I1{});
         MERV_PH_DONE();
         // phase 4
+        if constexpr (MODE == 2) res_pieces(std::integral_constant<int, 10>{}, I2{});  // ... and its B-early quarter
         if constexpr (has2) {
             dma_b(0, t + 2, BUF);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -734,7 +1114,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         k_tile(t + 1, I1{}, I0{}, std::false_type{});
     }
     k_tile(t, I0{}, I1{}, std::false_type{});
-    k_tile(t + 1, I1{}, std::integral_constant<int, 2>{}, std::false_type{});
+    k_tile(t + 1, I1{}, I2{}, std::false_type{});
 #undef MERV_PH_LOADED
 #undef MERV_PH_DONE
 #undef MERV_MX_MMA
@@ -743,7 +1123,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance the trailing group's extra barrier
     MERV_GSTAMP(4);  // K-loop done
 
-    gemm_epilogue<WTM, WTN, REMAP, ACT, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+#ifdef MERV_ABL_NOEPI  // ablation: prologue + K-loop + block turnover only
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
+    if constexpr (DIRECT) gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
+    else if constexpr (SPARE) gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 4, true>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+    else gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+#endif
     MERV_GSTAMP(10);  // part 1's stores are issued
 #ifdef MERV_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -768,34 +1157,53 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
     return e;
 }
 
-template <bool REMAP, int ACT, bool MX = false>
+template <bool REMAP, int ACT, int EPI, bool MX = false>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
-    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX>;
+    // 128 KB of operand buffers + (MX) 4 KB of block scales / (bf16) the 32 KB the epilogue stages its transpose in
+    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 32768);
+    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + 255) / 256, tilesN = a.N / 256;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
-template <int ACT>
-hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
-    if (a.out_group > 0 || a.res_row_mod > 0) {
-        if constexpr (ACT == ACT_NONE) return launch_8phase2<true, ACT>(a, s);
-        else return hipErrorInvalidValue;
-    }
-    return launch_8phase2<false, ACT>(a, s);
+// The epilogue mode of a launch (see EPI_*). Row remapping (patch embedding) and activations never come with a LayerScale in the
+// encoder stack: those combinations exist only in generic form.
+inline int epi_mode(const GemmArgs& a) {
+    if (a.row_stats) return a.lscale ? EPI_GENERIC : EPI_FOLD;
+    if (a.lscale) return (a.act == ACT_NONE && a.out_group <= 0 && a.res_row_mod <= 0) ? EPI_LS : EPI_GENERIC;
+    return EPI_PLAIN;
 }
 template <int ACT>
-hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) { return launch_8phase2<false, ACT, true>(a, s); }
+hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
+    const int epi = epi_mode(a);
+    if (a.out_group > 0 || a.res_row_mod > 0) {
+        if constexpr (ACT == ACT_NONE) {
+            if (epi == EPI_PLAIN) return launch_8phase2<true, ACT, EPI_PLAIN>(a, s);
+            if (epi == EPI_GENERIC) return launch_8phase2<true, ACT, EPI_GENERIC>(a, s);
+        }
+        return hipErrorInvalidValue;
+    }
+    switch (epi) {
+        case EPI_PLAIN: return launch_8phase2<false, ACT, EPI_PLAIN>(a, s);
+        case EPI_FOLD: return launch_8phase2<false, ACT, EPI_FOLD>(a, s);
+        case EPI_LS:
+            if constexpr (ACT == ACT_NONE) return launch_8phase2<false, ACT, EPI_LS>(a, s);
+            return hipErrorInvalidValue;
+        default: return launch_8phase2<false, ACT, EPI_GENERIC>(a, s);
+    }
+}
+template <int ACT>
+hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) { return launch_8phase2<false, ACT, EPI_GENERIC, true>(a, s); }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI>
 hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
     constexpr int LDS = NSTAGE * (BM + BN) * ROW_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(LDS >= WM * WN * (BM / WM) * 128, "epilogue staging must fit in the stage ring");
     static_assert(!STAGGER || WM * WN == 8, "stagger pairs the two waves of each SIMD: 8-wave blocks only");
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.N / BN;
@@ -804,11 +1212,22 @@ hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
 }
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, int ACT>
 hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-    if (a.out_group > 0 || a.res_row_mod > 0) {
-        if constexpr (ACT == ACT_NONE) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, true, ACT>(a, s);
-        else return hipErrorInvalidValue;  // row remapping is only instantiated for the plain (embedding) epilogue
+    const int epi = epi_mode(a);
+    if (a.out_group > 0 || a.res_row_mod > 0) {  // row remapping is only instantiated for the embedding's epilogues
+        if constexpr (ACT == ACT_NONE) {
+            if (epi == EPI_PLAIN) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, true, ACT, EPI_PLAIN>(a, s);
+            if (epi == EPI_GENERIC) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, true, ACT, EPI_GENERIC>(a, s);
+        }
+        return hipErrorInvalidValue;
     }
-    return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT>(a, s);
+    switch (epi) {
+        case EPI_PLAIN: return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT, EPI_PLAIN>(a, s);
+        case EPI_FOLD: return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT, EPI_FOLD>(a, s);
+        case EPI_LS:
+            if constexpr (ACT == ACT_NONE) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT, EPI_LS>(a, s);
+            return hipErrorInvalidValue;
+        default: return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, false, ACT, EPI_GENERIC>(a, s);
+    }
 }
 
 int g_gemm_variant = 0;
@@ -889,6 +1308,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0) return hipSuccess;
     GemmArgs a = a_in;
     if (g_gemm_group_m > 0) a.group_m = g_gemm_group_m;
+    if (a.stats_out && a.stats_ld <= 0) a.stats_ld = a.M;  // rows of the partials array: [N / 64][stats_ld][2]
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 8 != 0) return hipErrorInvalidValue;
@@ -921,7 +1341,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     rest.C = a.C + (size_t)rows1 * a.ldc;
     if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
     if (a.row_stats) rest.row_stats = a.row_stats + 2 * (size_t)rows1;
-    if (a.stats_out) rest.stats_out = a.stats_out + 2 * (size_t)rows1 * (a.N >> 6);
+    if (a.stats_out) rest.stats_out = a.stats_out + 2 * (size_t)rows1;  // same stats_ld: the rows below the first launch's
     if (a.mx_out_q) {  // rows1 is a multiple of 256: whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
         rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;
         rest.mx_out_scales = a.mx_out_scales + (size_t)(rows1 / 64) * 256;

@@ -30,10 +30,13 @@ struct GemmArgs {
     const float* ln_colsum;   // [N]
     // any launch whose output C is the residual stream a folded LayerNorm will read next: when stats_out is set the epilogue
     // also writes, per output row and per 64-column wave tile, {sum, M2 = sum of squared deviations from the tile's own mean}
-    // of the bf16-ROUNDED values it stores: stats_out[(m * (N / 64) + n / 64) * 2 .. +1]. launch_stats_finalize combines the
-    // N / 64 partials of a row (Chan's parallel variance: exact, no E[x^2] - mean^2 cancellation) into row_stats for the
-    // consuming GEMM, so no kernel re-reads the residual stream for LayerNorm.
+    // of the bf16-ROUNDED values it stores: stats_out[((n / 64) * stats_ld + m) * 2 .. +1] -- column tile major, so a wave's rows
+    // are consecutive and go out as one coalesced store per epilogue part (round 4; [m][n / 64] made every row an 8-byte
+    // partial-line write and doubled the epilogue's store instructions). launch_stats_finalize combines the N / 64 partials of
+    // a row (Chan's parallel variance: exact, no E[x^2] - mean^2 cancellation) into row_stats for the consuming GEMM, so no
+    // kernel re-reads the residual stream for LayerNorm.
     float* stats_out;
+    int stats_ld;             // rows of the partials array (0: M of this launch)
     // any launch: when mx_out_q is set the epilogue writes its (bf16-rounded) result as MXFP8 -- e4m3 [M, N] + block
     // scales in the layout of mx_quantize -- instead of bf16 C (the next GEMM's quantised input, e.g. fc1 -> fc2)
     uint8_t* mx_out_q;
@@ -89,9 +92,9 @@ hipError_t launch_row_stats(const RowStatsArgs& a, hipStream_t s);
 
 // Combine the per-64-column partials a producer GEMM's epilogue wrote (GemmArgs::stats_out) into stats[m] = {rstd, -mean * rstd}.
 struct StatsFinalizeArgs {
-    const float* parts;  // [M][nparts][2] = {sum, M2} over 64 columns each
+    const float* parts;  // [nparts][M][2] = {sum, M2} over 64 columns each
     float* stats;        // [M][2]
-    int M, nparts;       // D = 64 * nparts
+    int M, nparts;       // D = 64 * nparts (nparts <= 32)
     float eps;
 };
 hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s);

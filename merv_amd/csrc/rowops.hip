@@ -444,39 +444,33 @@ hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// 16 lanes per row (one 64-column partial each when D = 1024; rows with more partials loop): the partials of a row are 128
-// contiguous bytes, so a wave reads 4 rows = 512 contiguous bytes per instruction. Chan et al.'s combination of
-// (n, mean, M2): total mean first, then M2 = sum_i M2_i + 64 (mean_i - mean)^2.
+// One thread per row; the partials are [nparts][M][2] (column tile major), so a wave reads 512 contiguous bytes per column tile.
+// Chan et al.'s combination of (n, mean, M2): total mean first, then M2 = sum_i M2_i + 64 (mean_i - mean)^2, in tile order.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsFinalizeArgs p) {
-    const int sub = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool ok = row < p.M;
-    const float2* pr = (const float2*)p.parts + (size_t)(ok ? row : 0) * p.nparts;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= p.M) return;
+    const float2* pr = (const float2*)p.parts + row;
+    constexpr int MAXP = 32;
+    float2 v[MAXP];
     float tot = 0.f;
-    for (int i = sub; i < p.nparts; i += 16) tot += pr[i].x;
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) tot += __shfl_xor(tot, o, 64);
+    for (int i = 0; i < MAXP; ++i)
+        if (i < p.nparts) { v[i] = pr[(size_t)i * p.M]; tot += v[i].x; }
     const float D = 64.f * (float)p.nparts;
     const float mean = tot / D;
     float m2 = 0.f;
-    for (int i = sub; i < p.nparts; i += 16) {
-        const float2 v = pr[i];
-        const float d = v.x * (1.f / 64.f) - mean;
-        m2 += v.y + 64.f * d * d;
-    }
 #pragma unroll
-    for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o, 64);
-    if (ok && sub == 0) {
-        const float rstd = rsqrtf(m2 / D + p.eps);
-        *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
-    }
+    for (int i = 0; i < MAXP; ++i)
+        if (i < p.nparts) { const float d = v[i].x * (1.f / 64.f) - mean; m2 += v[i].y + 64.f * d * d; }
+    const float rstd = rsqrtf(m2 / D + p.eps);
+    *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
 }
 
 hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
-    if (a.nparts <= 0 || !a.parts || !a.stats) return hipErrorInvalidValue;
+    if (a.nparts <= 0 || a.nparts > 32 || !a.parts || !a.stats) return hipErrorInvalidValue;
     ProfScope pk(PROF_K_STATS, s, 0.0, 8.0 * a.M * (double)a.nparts + 8.0 * a.M);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 15) / 16), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

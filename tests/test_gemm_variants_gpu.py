@@ -77,13 +77,14 @@ def test_epilogue_layernorm_partials(dev, M, N, K, act):
     fn = {"none": lambda t: t, "gelu_erf": F.gelu, "gelu_tanh": lambda t: F.gelu(t, approximate="tanh"),
           "quick_gelu": lambda t: t * torch.sigmoid(1.702 * t)}[act]
     ref = x.float() + ls * fn(a.float() @ w.float().t() + bias)
-    parts = torch.full((M, N // 64, 2), float("nan"), device=dev)
+    parts = torch.full((N // 64, M, 2), float("nan"), device=dev)  # column tile major: a wave's rows are one coalesced store
     out = x.clone()
     check(lib.merv_debug_gemm_stats(ptr(a), ptr(w), ptr(out), ptr(bias), ptr(ls), ptr(out), M, N, K, ACT[act], ptr(parts),
                                     torch.cuda.current_stream(dev).cuda_stream), "merv_debug_gemm_stats")
     assert rel_l2(out, ref) < 6e-3, (M, N, K, act)
     o = out.float()
     assert torch.isfinite(parts).all()
+    parts = parts.transpose(0, 1)  # [M, N // 64, 2]
     mean = parts[..., 0].sum(1) / N
     m2 = (parts[..., 1] + 64 * (parts[..., 0] / 64 - mean[:, None]) ** 2).sum(1)
     assert torch.allclose(mean, o.mean(1), rtol=1e-4, atol=1e-5)
