@@ -288,15 +288,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         load_tile(0);
     }
     MERV_STAMP(1);
+    // Scores are wanted in log2 units, s' = (q . k) scale log2(e), so that the MFMA chain -- seeded with -m -- leaves the argument
+    // of the exponential itself (round 4). The factor goes into Q once per block: 1 when the producer folded it into the q rows of
+    // the qkv weight (AttnArgs::q_prescaled: no extra rounding anywhere), otherwise q is scaled and re-rounded to bf16 here.
+    const float qs = p.q_prescaled ? 1.0f : sc;
+    auto scale_q = [&](u32x4 w) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = pack2bf(bflo(w[j]) * qs, bfhi(w[j]) * qs);
+        return __builtin_bit_cast(bf16x8, w);
+    };
     bf16x8 qf[QPW][4], qx[4];
 #pragma unroll
     for (int qi = 0; qi < QPW; ++qi)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[qi][s] = __builtin_bit_cast(bf16x8, qraw[qi][s]);
+        for (int s = 0; s < 4; ++s) qf[qi][s] = scale_q(qraw[qi][s]);
     if constexpr (XQ) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qx[s] = __builtin_bit_cast(bf16x8, qxraw[s]);
+        for (int s = 0; s < 4; ++s) qx[s] = scale_q(qxraw[s]);
     }
+    const float psum_limit = fast_exp2(p.rescale_thr);  // a lane's 32 exponentials may sum to this before its reference moves
     // One key tile. TAILK (compile time): 0 = decide at run time whether the tile is the ragged last one; 1 = a full tile;
     // 2 = the resident kernel's last tile (sequences of 257 .. 264 tokens: 1 .. 8 keys, see tile_softmax).
     auto tile_body = [&](const int t, auto tailk_tag) {
@@ -326,7 +336,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         //      tiles the score registers would not fit and each tile is multiplied right before its softmax ----
         constexpr bool S_FIRST = QPW <= 2;
         f32x16 sacc[S_FIRST ? QPW : 1][2];
-        auto scores = [&](const bf16x8(&qfr)[4], f32x16(&sa)[2]) {
+        // seed: this lane's (= this query's) value for all 32 of its score registers: 0, or -m so that the chain ends on s' - m
+        auto scores = [&](const bf16x8(&qfr)[4], f32x16(&sa)[2], const float seed) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 if (kb == 1 && !both_halves) continue;
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 const char* krow = k_t + key * KROW;
                 const int sw = kswz(key);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sa[kb][i] = 0.f;
+                for (int i = 0; i < 16; ++i) sa[kb][i] = seed;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
@@ -342,15 +353,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 }
             }
         };
-        // One lane's share of a score tile -> exponentials in place, returns their sum; m_new = max(m_old, tile max) * log2e-scaled.
+        // One lane's share of a score tile (scores s' in log2 units, seed 0) -> exponentials against the exact running maximum in
+        // place, returns their sum; m_new = max(m_old, tile max).
         // NE = 16: elements of both 32-key halves (the second only when it holds real keys), masked on the tail tile.
         // NE = 4 (the resident kernel's tail tile: sequences of 257 .. 264 tokens leave 1 .. 8 keys there, i.e. elements 0 .. 3 of
         // the first half in both half-waves): 4 masks / exponentials instead of 32 compares and 16 exponentials; elements 4 .. 7
         // are zeroed for the one P.V step that still runs (keys 0 .. 15 of the tile).
-        auto tile_softmax = [&](auto ne_tag, f32x16(&sa)[2], float m_old, float& m_new) -> float {
+        auto mask_tail = [&](auto ne_tag, f32x16(&sa)[2]) {
             constexpr int NE = decltype(ne_tag)::value;
             constexpr int NKB = NE == 16 ? 2 : 1;
-            float mx = -INFINITY;
             if (tail) {
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
@@ -360,27 +371,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                         if (key >= L) sa[kb][i] = -INFINITY;  // (covers the skipped half too: its registers are stale)
                     }
             }
+        };
+        auto tile_softmax = [&](auto ne_tag, f32x16(&sa)[2], float m_old, float& m_new) -> float {
+            constexpr int NE = decltype(ne_tag)::value;
+            constexpr int NKB = NE == 16 ? 2 : 1;
+            float mx = -INFINITY;
+            mask_tail(ne_tag, sa);
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int i = 0; i < NE; ++i) mx = fmaxf(mx, sa[kb][i]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;  // sc > 0: max commutes with the scaling
-            // Deferred max (cdna_hip_programming.md T13): the reference m only has to keep the exponentials in range, not be the
-            // exact running maximum. It moves when this tile's maximum exceeds it by more than thr binary orders (always on the
-            // first tile: m_old = -inf); otherwise the tile is exponentiated against the old reference (values up to 2^thr: fp32
-            // sums and bf16 P keep their relative precision) and the 32-multiply rescale of O below is skipped. With the exact
-            // maximum some query of the wave moved it on nearly every tile (random scores: P(no move) = (1 - 1/t)^32 at tile t),
-            // i.e. ~36 VALU per (query tile, key tile) pair on a VALU-issue-bound kernel.
-            m_new = mx > m_old + p.rescale_thr ? mx : m_old;
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            m_new = fmaxf(mx, m_old);
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (kb == 1 && !both_halves) continue;
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
-                    const float e = fast_exp2(fmaf(sa[kb][i], sc, -m_new));
+                    const float e = fast_exp2(sa[kb][i] - m_new);
                     sa[kb][i] = e;
                     psum += e;
                 }
@@ -391,24 +402,61 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             }
             return psum;
         };
+        // The common form (deferred max, cdna_hip_programming.md T13, without a maximum): the chain was seeded with -m, the
+        // registers hold s' - m, and the tile costs one v_exp and one v_add per score -- no v_max, no v_fma. The reference m only
+        // has to keep the exponentials in range: a lane's 32 values are >= 0, so "their sum <= 2^thr" bounds every one of them
+        // (fp32 sums and bf16 P keep their relative precision up to there); a larger or non-finite sum sends the WAVE back through
+        // the exact form above for this tile (tile_body), which also moves m.
+        auto tile_exp = [&](auto ne_tag, f32x16(&sa)[2]) -> float {
+            constexpr int NE = decltype(ne_tag)::value;
+            constexpr int NKB = NE == 16 ? 2 : 1;
+            mask_tail(ne_tag, sa);
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float e = fast_exp2(sa[kb][i]);
+                    sa[kb][i] = e;
+                    psum += e;
+                }
+            }
+            if constexpr (NE < 8) {
+#pragma unroll
+                for (int i = NE; i < 8; ++i) sa[0][i] = 0.f;
+            }
+            return psum;
+        };
+        // the first tile has no reference yet (m = -inf): seed 0 and the exact form
         if constexpr (S_FIRST) {
 #pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi]);
+            for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi], t == 0 ? 0.f : -m_run[qi]);
         }
+        using NE_t = std::integral_constant<int, TAILK == 2 ? 4 : 16>;
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
-            if constexpr (!S_FIRST) scores(qf[qi], sa);
-            // ---- online softmax (this lane: one query, 32 of the tile's 64 keys); exponent = fma(s, c, -m c) ----
-            float m_new;
-            const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sa, m_run[qi], m_new);
-            if (!__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
-                const float alpha = fast_exp2(m_run[qi] - m_new);
-                l_run[qi] *= alpha;
+            if constexpr (!S_FIRST) scores(qf[qi], sa, t == 0 ? 0.f : -m_run[qi]);
+            // ---- online softmax (this lane: one query, 32 of the tile's 64 keys) ----
+            float psum = 0.f;
+            bool exact = t == 0;
+            if (!exact) {
+                psum = tile_exp(NE_t{}, sa);
+                exact = !__all(psum <= psum_limit);  // (a NaN or an infinite sum fails the comparison too)
+                if (exact) scores(qf[qi], sa, 0.f);  // rare: this tile again from its raw scores
+            }
+            if (exact) {
+                float m_new;
+                psum = tile_softmax(NE_t{}, sa, m_run[qi], m_new);
+                if (t > 0 && !__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
+                    const float alpha = fast_exp2(m_run[qi] - m_new);
+                    l_run[qi] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { oacc[qi][0][i] *= alpha; oacc[qi][1][i] *= alpha; }
-                m_run[qi] = m_new;
+                    for (int i = 0; i < 16; ++i) { oacc[qi][0][i] *= alpha; oacc[qi][1][i] *= alpha; }
+                }
+                m_run[qi] = m_new;  // (first tile: O and l are still zero, nothing to rescale)
             }
             l_run[qi] += psum;
 
@@ -432,7 +480,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         if constexpr (XQ) {
             if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
                 f32x16 sx[2];
-                scores(qx, sx);
+                scores(qx, sx, 0.f);
                 float mx;  // the tile's own maximum (finite: key kv0 of every tile is a real key); partials are merged after the loop
                 const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sx, -INFINITY, mx);
                 f32x16 ox[2];

@@ -95,6 +95,7 @@ struct merv_encoder {
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr float ATTN_SCALE = 0.125f;  // 1 / sqrt(head_dim = 64)
 
 extern "C" int merv_encoder_create(const merv_encoder_desc* desc, const merv_encoder_weights* w, merv_encoder** out) {
     MERV_CHECK(desc && w && out, "merv_encoder_create: null argument");
@@ -213,21 +214,22 @@ extern "C" int merv_encoder_enable_ln_fold(merv_encoder* e, void* buf, size_t by
     const int D = e->d.dim, H = e->d.mlp_dim;
     char* p = (char*)buf;
     e->fl.assign(e->d.layers, FoldLayer{});
+    // scale_rows / row_scale: the q rows of the qkv weight also take the attention's scale * log2(e) (AttnArgs::q_prescaled)
     auto fold = [&](const void* w, const float* gamma, const float* beta, const float* bias, int N, int K, const bf16_t*& wf,
-                    const float*& cs, const float*& db) -> hipError_t {
+                    const float*& cs, const float*& db, int scale_rows, float row_scale) -> hipError_t {
         bf16_t* wd = (bf16_t*)p;
         float* csd = (float*)(p + align_up((size_t)N * K * 2, 256));
         float* dbd = (float*)((char*)csd + align_up((size_t)N * 4, 256));
         p += fold_weight_bytes(N, K);
         wf = wd; cs = csd; db = dbd;
-        LnFoldArgs a{(const bf16_t*)w, gamma, beta, bias, wd, csd, dbd, N, K};
+        LnFoldArgs a{(const bf16_t*)w, gamma, beta, bias, wd, csd, dbd, N, K, scale_rows, row_scale};
         return launch_ln_fold(a, s);
     };
     for (int i = 0; i < e->d.layers; ++i) {
         const merv_layer_weights& L = e->layers[i];
         FoldLayer& f = e->fl[i];
-        MERV_HIP(fold(L.qkv_w, L.ln1_w, L.ln1_b, L.qkv_b, 3 * D, D, f.qkv_w, f.qkv_cs, f.qkv_db));
-        MERV_HIP(fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, H, D, f.fc1_w, f.fc1_cs, f.fc1_db));
+        MERV_HIP(fold(L.qkv_w, L.ln1_w, L.ln1_b, L.qkv_b, 3 * D, D, f.qkv_w, f.qkv_cs, f.qkv_db, D, ATTN_SCALE * 1.4426950408889634f));
+        MERV_HIP(fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, H, D, f.fc1_w, f.fc1_cs, f.fc1_db, 0, 1.0f));
     }
     e->fold = true;
     return 0;
@@ -330,7 +332,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     MERV_CHECK(workspace_bytes >= ws.total, "merv_encoder_forward: workspace too small");
 
     const int D = d.dim, nseq = batch * seq_per_video, ntok = e->ntok, M = nseq * ntok;
-    const float scale = 0.125f;  // 1/sqrt(64)
+    const float scale = ATTN_SCALE;
 
     // ---- patch / tubelet embedding: im2col + GEMM (+bias +pos), rows scattered past the prefix tokens ----
     {
@@ -419,6 +421,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
             else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
+            at.q_prescaled = folded;  // the folded qkv weight carries scale * log2(e) in its q rows
             if (mx_proj) { at.mx_q = ws.aq; at.mx_scales = ws.asc; at.mx_groups = mx_groups; }
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);

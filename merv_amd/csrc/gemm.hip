@@ -208,30 +208,9 @@ template <int EPI>
 constexpr bool epi_needs_row_stats = (EPI == EPI_GENERIC || EPI == EPI_FOLD);
 
 // ---- epilogue through LDS (shared by all tile configurations) ----
-// Eight-phase kernel: every wave owns sixteen 1-KiB LDS slots, the destinations of its own DMA pieces (8 per buffer). In the LAST
-// K-tile they are dead one after the other -- buffer 0 from its first phase, the early quarters of buffer 1 from phases 3 / 4 -- and
-// the residual rows of the wave's output tile (16 pieces of 8 rows x 128 B, lane-linear: exactly what the epilogue's read-back
-// lane wants) are brought there by LDS-DMA under the last MFMAs (pieces 0-11; 12-15 as register loads at the top of the epilogue).
-MERV_DEVICE int own_slot_a(int buf, int u, int sq, int wave) { return buf * 65536 + (u * 16 + sq * 8 + wave) * 1024; }
-MERV_DEVICE int own_slot_b(int buf, int u, int sq, int wave) {
-    return buf * 65536 + 32768 + (((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3)) * 1024;
-}
-MERV_DEVICE int res_slot(int q, int wave) {  // q = 0 .. 11, compile-time at every call site
-    if (q < 4) return own_slot_a(0, q >> 1, q & 1, wave);
-    if (q < 8) return own_slot_b(0, (q - 4) >> 1, (q - 4) & 1, wave);
-    if (q < 10) return own_slot_a(1, q - 8, 0, wave);
-    return own_slot_b(1, q - 10, 0, wave);
-}
-constexpr int RES_LDS_PIECES = 12;
-constexpr int SPARE_LDS_BASE = 131072;  // the 32 KB above the two operand buffers (160 KB blocks)
-
-// SPARE (eight-phase bf16 kernels, MSPLIT = 4): the transpose is staged in the 32 KB of LDS above the operand buffers (4 KB per
-// wave, 32 rows per part), a region the K-loop never touches -- no block barrier between the last MFMA and the first store -- and
-// the residual rows come from the wave's own LDS slots (above) instead of global memory.
-template <int WTM_FULL, int WTN, bool REMAP, int ACT, int EPI, int MSPLIT = 1, bool SPARE = false>
+template <int WTM_FULL, int WTN, bool REMAP, int ACT, int EPI, int MSPLIT = 1>
 MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FULL / 16], char* smem, int wave, int lane, int m0,
                                int n0, int wr, int wc) {
-    static_assert(!SPARE || (WTM_FULL == 128 && MSPLIT == 4 && !REMAP), "spare-region staging: 128-row wave tiles in four parts");
     // MSPLIT > 1: the wave's rows are finished in MSPLIT passes of WTM rows each (bounds the registers the residual
     // rows and offsets take next to a 128-register accumulator)
     constexpr int WTM = WTM_FULL / MSPLIT;
@@ -274,18 +253,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 }
         }
     }
-    char* stg = smem + (SPARE ? SPARE_LDS_BASE : 0) + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
-    u32x4 res_tail[4];  // SPARE: residual pieces 12-15 (the last part's rows), requested now
-    if constexpr (SPARE) {
-        if (p.res) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                int m = m0 + wr * WTM_FULL + (RES_LDS_PIECES + it) * 8 + (elane >> 3);
-                m = m < p.M ? m : p.M - 1;
-                res_tail[it] = *(const u32x4*)(p.res + (size_t)((uint32_t)m * (uint32_t)p.ldres) + wn0 + ec * 8);
-            }
-        }
-    }
+    char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
         if (part == 1) MERV_GSTAMP(8);  // part 0's stores are issued
@@ -309,19 +277,16 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         }
         // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
         // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
-        if constexpr (!SPARE) {
-            if (p.res) {
+        if (p.res) {
 #pragma unroll
-                for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
-            } else {
+            for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
+        } else {
 #pragma unroll
-                for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
-            }
+            for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
         }
-        // part 0: every wave is done with the stage ring (SPARE: the staging region is not part of it); later parts: this wave's
-        // reads of its staging region returned
+        // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
         if (part == 0) MERV_GSTAMP(5);  // epilogue operands and part 0's residual rows requested
-        if (part == 0 && !SPARE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (part == 0) MERV_GSTAMP(6);  // staging barrier passed
 #pragma unroll
@@ -341,21 +306,6 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-wave ordering is enough
         if (part == 0) MERV_GSTAMP(7);  // part 0 scaled, activated, packed and staged
         else MERV_GSTAMP(9);
-        if constexpr (SPARE) {
-            if (p.res) {
-                // the DMA pieces were issued by THIS wave into its own slots: its own vmcnt orders them for its own reads
-                if (part == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < EP_IT; ++it) {
-                    const int q = part * EP_IT + it;
-                    if (q < RES_LDS_PIECES) resv[it] = *(const u32x4*)(smem + res_slot(q < RES_LDS_PIECES ? q : 0, wave) + elane * 16);
-                    else resv[it] = res_tail[q >= RES_LDS_PIECES ? q - RES_LDS_PIECES : 0];
-                }
-            } else {
-#pragma unroll
-                for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
-            }
-        }
         float2 row_part = float2{0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
@@ -596,9 +546,6 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
 #ifndef MERV_GEMM_EPILOGUE
 #define MERV_GEMM_EPILOGUE 2
 #endif
-#ifndef MERV_GEMM_SPARE  // A/B builds: -DMERV_GEMM_SPARE=0 = staging inside the stage ring behind a block barrier, residual rows by register loads
-#define MERV_GEMM_SPARE 1
-#endif
 template <int ACT>
 constexpr bool gemm_direct_epilogue = (MERV_GEMM_EPILOGUE == 1) || (MERV_GEMM_EPILOGUE == 2 && ACT != ACT_NONE);
 
@@ -831,7 +778,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
     constexpr bool DIRECT = gemm_direct_epilogue<ACT> && !MX;  // MX: the W block scales are laid out by (unpermuted) row fragment
     static_assert(!MX || EPI == EPI_GENERIC, "MXFP8 launches take the generic epilogue");
-    constexpr bool SPARE = MERV_GEMM_SPARE && !MX && !DIRECT && !REMAP;  // 160 KB blocks: epilogue staged above the buffers, residual rows by LDS-DMA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MERV_GSTAMP_REAL(0);
     MERV_GSTAMP_HWID(14);
@@ -1041,40 +987,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // phase 2 and its A-late quarter in phase 3, so phases 1 and 2 each retire one of them before their first barrier (the
     // wave's queue then holds, youngest last: [the quarter wanted][the other late quarter or nothing][tile 1: A-early, B-early,
     // (MX scales), B-late, (A-late)] -> all but the 8 (MX: 9) youngest), one phase ahead of the read as the ordering rule asks.
-    // SPARE, last K-tile only: residual piece q of this wave's output tile (rows 8 q .. 8 q + 7) into the wave's own dead slot
-    const bool res_dma = SPARE && p.res != nullptr;
-    auto res_pieces = [&](auto q0_tag, auto n_tag) {
-        if constexpr (SPARE) {
-            if (res_dma) {
-                constexpr int q0 = decltype(q0_tag)::value, n = decltype(n_tag)::value;
-                int l2 = lane;
-                asm volatile("" : "+v"(l2));  // keep the address arithmetic here (not hoisted over the K-loop)
-#pragma unroll
-                for (int q = q0; q < q0 + n; ++q) {
-                    int row = m0 + wr * WTM + q * 8 + (l2 >> 3);
-                    row = row < p.M ? row : p.M - 1;
-                    const bf16_t* src = p.res + (size_t)((uint32_t)row * (uint32_t)p.ldres) + (n0 + wc * WTN) + (l2 & 7) * 8;
-                    dma((const char*)src, res_slot(q, wave));
-                }
-            }
-        }
-    };
     using I2 = std::integral_constant<int, 2>;
-    using I4 = std::integral_constant<int, 4>;
     auto k_tile = [&](int t, auto buf_tag, auto mode_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
         static_assert(!FIRST || MODE == 0, "the first tile always has two successors");
-        static_assert(MODE != 2 || BUF == 1, "the last tile lives in buffer 1 (res_slot assumes buffer 0 is dead)");
         // phase 1
         read_scales(BUF);
         read_w(BUF, 0);
         __builtin_amdgcn_sched_barrier(0);
         read_a(BUF, 0);
         if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
-        if constexpr (MODE == 2) res_pieces(I0{}, I4{});  // buffer 0 is dead: pieces 0-3 -> this wave's A slots there
         if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I0{});
@@ -1082,7 +1007,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         // phase 2
         read_w(BUF, 1);
         if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
-        if constexpr (MODE == 2) res_pieces(I4{}, I4{});  // pieces 4-7 -> its B slots of buffer 0
         if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I1{});
@@ -1090,12 +1014,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         // phase 3
         read_a(BUF, 1);
         if constexpr (has2) dma_a(0, t + 2, BUF);
-        if constexpr (MODE == 2) res_pieces(std::integral_constant<int, 8>{}, I2{});  // where tile t + 2's A-early quarter would go
         MERV_PH_LOADED();
         quadrant(I1{}, I1{});
         MERV_PH_DONE();
         // phase 4
-        if constexpr (MODE == 2) res_pieces(std::integral_constant<int, 10>{}, I2{});  // ... and its B-early quarter
         if constexpr (has2) {
             dma_b(0, t + 2, BUF);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1130,7 +1052,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
     if constexpr (DIRECT) gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
-    else if constexpr (SPARE) gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 4, true>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     else gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
 #endif
     MERV_GSTAMP(10);  // part 1's stores are issued
@@ -1159,8 +1080,7 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
 
 template <bool REMAP, int ACT, int EPI, bool MX = false>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
-    // 128 KB of operand buffers + (MX) 4 KB of block scales / (bf16) the 32 KB the epilogue stages its transpose in
-    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 32768);
+    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
     auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;

@@ -110,6 +110,10 @@ struct LnFoldArgs {
     float* colsum;        // [N]
     float* dbias;         // [N]
     int N, K;
+    // rows n < scale_rows are additionally multiplied by row_scale BEFORE the one rounding to bf16 (the q rows of a qkv weight
+    // take the attention's scale * log2(e) this way: AttnArgs::q_prescaled); dbias likewise, colsum of the rounded values
+    int scale_rows;
+    float row_scale;
 };
 hipError_t launch_ln_fold(const LnFoldArgs& a, hipStream_t s);
 
@@ -128,6 +132,9 @@ struct AttnArgs {
     uint8_t* mx_q;
     uint8_t* mx_scales;
     int mx_groups;
+    // the q third of qkv already carries scale * log2(e) (folded into the q rows of the qkv weight and bias by launch_ln_fold):
+    // the kernel then uses q as it is instead of scaling and re-rounding it
+    int q_prescaled;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 

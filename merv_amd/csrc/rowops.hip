@@ -130,10 +130,11 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(LnFoldArgs p) {
     const int n = blockIdx.x;
     const bf16_t* wr = p.w + (size_t)n * p.K;
     bf16_t* wo = p.wf + (size_t)n * p.K;
+    const float rsc = n < p.scale_rows ? p.row_scale : 1.0f;
     float cs = 0.f, db = 0.f;
     for (int k = threadIdx.x; k < p.K; k += 256) {
         const float w = bf2f(wr[k]);
-        const bf16_t r = f2bf(w * p.gamma[k]);
+        const bf16_t r = f2bf(w * p.gamma[k] * rsc);
         wo[k] = r;
         cs += bf2f(r);
         db += w * p.beta[k];
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(LnFoldArgs p) {
     __syncthreads();
     if (threadIdx.x == 0) {
         p.colsum[n] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        p.dbias[n] = red[1][0] + red[1][1] + red[1][2] + red[1][3] + (p.bias ? p.bias[n] : 0.f);
+        p.dbias[n] = (red[1][0] + red[1][1] + red[1][2] + red[1][3] + (p.bias ? p.bias[n] : 0.f)) * rsc;
     }
 }
 
@@ -444,33 +445,44 @@ hipError_t launch_prefix(const PrefixArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// One thread per row; the partials are [nparts][M][2] (column tile major), so a wave reads 512 contiguous bytes per column tile.
-// Chan et al.'s combination of (n, mean, M2): total mean first, then M2 = sum_i M2_i + 64 (mean_i - mean)^2, in tile order.
+// Four lanes per row (lane sub takes column tiles sub, sub + 4, ...: 16 rows x 8 B = one 128-byte line per tile and instruction;
+// one thread per row left 4 waves per CU waiting on their loads); the partials are [nparts][M][2] (column tile major).
+// Chan et al.'s combination of (n, mean, M2): total mean first, then M2 = sum_i M2_i + 64 (mean_i - mean)^2.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsFinalizeArgs p) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= p.M) return;
-    const float2* pr = (const float2*)p.parts + row;
-    constexpr int MAXP = 32;
+    const int sub = threadIdx.x & 3;
+    const int row = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool ok = row < p.M;
+    const float2* pr = (const float2*)p.parts + (ok ? row : 0);
+    constexpr int MAXP = 8;  // column tiles per lane (nparts <= 32)
     float2 v[MAXP];
     float tot = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i)
-        if (i < p.nparts) { v[i] = pr[(size_t)i * p.M]; tot += v[i].x; }
+    for (int i = 0; i < MAXP; ++i) {
+        const int t = sub + 4 * i;
+        v[i] = t < p.nparts ? pr[(size_t)t * p.M] : float2{0.f, 0.f};
+        tot += v[i].x;
+    }
+    tot += __shfl_xor(tot, 1, 64);
+    tot += __shfl_xor(tot, 2, 64);
     const float D = 64.f * (float)p.nparts;
     const float mean = tot / D;
     float m2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i)
-        if (i < p.nparts) { const float d = v[i].x * (1.f / 64.f) - mean; m2 += v[i].y + 64.f * d * d; }
-    const float rstd = rsqrtf(m2 / D + p.eps);
-    *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
+        if (sub + 4 * i < p.nparts) { const float d = v[i].x * (1.f / 64.f) - mean; m2 += v[i].y + 64.f * d * d; }
+    m2 += __shfl_xor(m2, 1, 64);
+    m2 += __shfl_xor(m2, 2, 64);
+    if (ok && sub == 0) {
+        const float rstd = rsqrtf(m2 / D + p.eps);
+        *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
+    }
 }
 
 hipError_t launch_stats_finalize(const StatsFinalizeArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.nparts <= 0 || a.nparts > 32 || !a.parts || !a.stats) return hipErrorInvalidValue;
     ProfScope pk(PROF_K_STATS, s, 0.0, 8.0 * a.M * (double)a.nparts + 8.0 * a.M);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 255) / 256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((a.M + 63) / 64), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
