@@ -349,6 +349,40 @@ size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
+/*
+ * The whole decode step -- every layer's five operations and the final norm + lm_head -- as ONE launch (round 4): the operations are
+ * block ranges of one grid in dependency order; a block requests its first weights, then waits on its producer's arrival counter
+ * (write-through hand-off, bounded spins), so the HBM weight stream does not stop at operation boundaries. Same arithmetic, rounding
+ * points and reduction orders as the calls above: the logits are bit-identical to the 5-launches-per-layer sequence. Replaces the same
+ * reference code (merv/models/vidlms/merv.py:818-825 -> the per-token LlamaForCausalLM.forward).
+ *   layers    device array of L merv_decode_layer entries (device pointers; bq / bk / bv may be NULL)
+ *   x         [D] bf16, holds the token's embedding on entry (it is the residual stream of the step)
+ *   counters  merv_decode_chain_counter_bytes(L) bytes of device memory, zeroed by every call (a memset on the stream)
+ *   err       one device word, only ever OR-ed: non-zero after a step means a wait gave up after 0.2 s (results invalid)
+ * Requirements: hd == 128; H*hd, Hkv*hd, D, I, V multiples of 8; 512 <= D <= 8192; no o_proj / MLP biases.
+ */
+typedef struct merv_decode_layer {
+    const void *wq, *wk, *wv, *wo, *wg, *wu, *wd;  /* nn.Linear weights [out, in] bf16 */
+    const void *ln1, *ln2;                         /* input_layernorm / post_attention_layernorm weights [D] bf16 */
+    const void *bq, *bk, *bv;                      /* q / k / v biases bf16 or NULL */
+    void *k_cache, *v_cache;                       /* [Hkv, max_len, hd] bf16 */
+} merv_decode_layer;
+typedef struct merv_decode_chain {
+    const merv_decode_layer *layers;
+    int32_t L, D, I, H, Hkv, hd, V, max_len, nsplit;
+    void *x, *q, *k, *v, *ao, *mid;                /* [D], [H hd], [Hkv hd], [Hkv hd], [H hd], [I] bf16 */
+    float *logits;                                 /* [V] */
+    const void *cos_t, *sin_t;                     /* [max_len, hd] bf16 */
+    const int64_t *pos;                            /* device int64 */
+    float *attn_ws;                                /* merv_decode_attention_fused_workspace_floats(H, nsplit) floats, zeroed once */
+    const void *final_norm, *lm_head;              /* [D], [V, D] bf16 */
+    void *counters;
+    uint32_t *err;
+    float eps, scale;
+} merv_decode_chain;
+size_t merv_decode_chain_counter_bytes(int32_t layers);
+int merv_decode_chain_step(const merv_decode_chain *c, void *stream);
+
 /* The attention step of timm's AttentionPoolLatent (global_pool='map': what the SigLIP ids without `all-no-cls` return,
  * siglip.py:46-63): one learnt query per head against every token of a frame. kv [nseq*ntok, 2*D] bf16 = [k | v] rows (the kv
  * Linear's output), q [D] fp32 = q Linear of the latent, out [nseq, D] bf16; D = heads * 64, ntok <= 1024. */

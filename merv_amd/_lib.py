@@ -51,6 +51,16 @@ class EncoderWeights(C.Structure):
 
 # name -> (restype, argtypes); every symbol include/merv_hip.h declares
 _i32, _i64, _f32, _f64, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
+
+
+class DecodeChain(C.Structure):
+    """include/merv_hip.h `merv_decode_chain`: the whole decode step as one launch (field order is the ABI)."""
+    _fields_ = ([("layers", C.c_void_p)] + [(n, C.c_int32) for n in ("L", "D", "I", "H", "Hkv", "hd", "V", "max_len", "nsplit")] +
+                [(n, C.c_void_p) for n in ("x", "q", "k", "v", "ao", "mid", "logits", "cos_t", "sin_t", "pos", "attn_ws", "final_norm",
+                                           "lm_head", "counters", "err")] + [("eps", C.c_float), ("scale", C.c_float)])
+
+
+DECODE_LAYER_FIELDS = ("wq", "wk", "wv", "wo", "wg", "wu", "wd", "ln1", "ln2", "bq", "bk", "bv", "k_cache", "v_cache")  # merv_decode_layer
 ABI_VERSION = 2  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
 
 SIGNATURES = {
@@ -105,6 +115,8 @@ SIGNATURES = {
     "merv_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_attention_fused_workspace_floats": (_sz, [_i32, _i32]),
     "merv_decode_attention_fused": (C.c_int, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "merv_decode_chain_counter_bytes": (_sz, [_i32]),
+    "merv_decode_chain_step": (C.c_int, [_vp, _vp]),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_prof_enable": (None, [_i32]),
     "merv_prof_reset": (None, []),

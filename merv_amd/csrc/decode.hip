@@ -34,6 +34,41 @@ MERV_DEVICE void unpack8f(const u32x4& p, float (&f)[8]) {
 }
 MERV_DEVICE float round_bf(float x) { return bf2f(f2bf(x)); }
 
+// sum of squares of the 16-byte chunks c with (c / 64) % 4 == part of a row (one wave; all 64 lanes get the result), in two
+// steps so that a caller can put other loads between the request of the first four chunks per lane (K <= 8192: all of them) and
+// their use. The row's mean(x^2) is ALWAYS formed as ((part 0 + part 1) + part 2) + part 3, whether one wave computes the four
+// parts (rmsnorm_kernel) or the four waves of a GEMV block one each (fused norm): the fused launches stay bit-identical to
+// RMSNorm + GEMV.
+MERV_DEVICE void sumsq_request(const bf16_t* x, int nchunk, int lane, int part, u32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * part + 256 * i;
+        v[i] = c < nchunk ? *(const u32x4*)(x + c * 8) : u32x4{0u, 0u, 0u, 0u};  // (a zero chunk adds exactly nothing)
+    }
+}
+MERV_DEVICE float sumsq_finish(const bf16_t* x, int nchunk, int lane, int part, const u32x4 (&v)[4]) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8f(v[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+    for (int c = lane + 64 * part + 1024; c < nchunk; c += 256) {
+        float f[8];
+        unpack8f(*(const u32x4*)(x + c * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+    }
+    return wave_sum64(ss);
+}
+MERV_DEVICE float sumsq_part(const bf16_t* x, int nchunk, int lane, int part) {
+    u32x4 v[4];
+    sumsq_request(x, nchunk, lane, part, v);
+    return sumsq_finish(x, nchunk, lane, part, v);
+}
+
 // ---- RMSNorm: one wave per row ----
 __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
     const int lane = threadIdx.x & 63;
@@ -41,14 +76,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
     if (row >= p.rows) return;
     const bf16_t* x = p.x + (size_t)row * p.D;
     const int nchunk = p.D >> 3;
-    float ss = 0.f;
-    for (int c = lane; c < nchunk; c += 64) {
-        float f[8];
-        unpack8f(*(const u32x4*)(x + c * 8), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
-    }
-    const float rstd = rsqrtf(wave_sum64(ss) / (float)p.D + p.eps);
+    const float ss = ((sumsq_part(x, nchunk, lane, 0) + sumsq_part(x, nchunk, lane, 1)) + sumsq_part(x, nchunk, lane, 2)) +
+                     sumsq_part(x, nchunk, lane, 3);
+    const float rstd = rsqrtf(ss / (float)p.D + p.eps);
     bf16_t* y = p.y + (size_t)row * p.D;
     for (int c = lane; c < nchunk; c += 64) {
         float f[8], w[8];
@@ -62,16 +92,92 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
     }
 }
 
+// ---- hand-off policies: how a kernel body meets the data other workgroups produce / consume ----
+// Stand-alone launches: inputs are complete before the launch starts and outputs are read after it ends.
+struct NoHandoff {
+    static constexpr bool chained = false;
+    MERV_DEVICE void wait_input(int) const {}
+    MERV_DEVICE u32x4 load16(const bf16_t* base, int elem, int) const { return *(const u32x4*)(base + elem); }
+    MERV_DEVICE float load_bf16(const bf16_t* base, int elem, int) const { return bf2f(base[elem]); }
+    MERV_DEVICE void signal() const {}
+};
+// One launch for the whole decode step (decode_chain_kernel): an operation's workgroups follow its producer's in block-index
+// order, request their first weights, and only then wait for the producer's arrival counter. The in-launch hand-off is the
+// write-through form of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms" (first table row): every
+// handed-off byte is stored sc1 (4 / 8 bytes, relaxed agent-scope atomic stores) by ONE lane of its workgroup, which then waits
+// vmcnt(0) and adds to the operation's counter (agent-scope atomic); a consumer workgroup polls the counter with sc1 loads from
+// one wave, the others wait at a workgroup barrier that wave then joins, and EVERY load of handed-off bytes is an sc1 load
+// (buffer_load ... sc1 / relaxed agent-scope atomic loads) -- no release / acquire fences. Counters are zeroed by a memset
+// node ahead of the launch (one per step); every spin is bounded (a stuck chain sets *err and runs on, it never hangs).
+constexpr int CHAIN_SHARDS = 8;          // arrival counter shards per operation, one 128-byte line each
+constexpr int CHAIN_OP_STRIDE = CHAIN_SHARDS * 32;  // uint32 per operation
+struct ChainHandoff {
+    static constexpr bool chained = true;
+    const unsigned* dep;   // producer's counter shards (nullptr: inputs were complete before the launch)
+    unsigned expected;     // arrivals that complete the producer
+    unsigned* mine;        // this operation's counter shards (nullptr: nothing in this launch consumes the outputs)
+    unsigned* err;
+    int block;
+    MERV_DEVICE void wait_input(int wave) const {
+#ifdef MERV_CHAIN_ABL_NOWAIT  // ablation (wrong results): how fast does the merged grid stream without any hand-off?
+        return;
+#endif
+        if (dep == nullptr) return;  // (uniform)
+        if (wave == 0) {
+            const int lane = threadIdx.x & 63;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+            for (;;) {
+                unsigned v = lane < CHAIN_SHARDS ? __hip_atomic_load(dep + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (__builtin_amdgcn_readfirstlane(v) >= expected) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {  // 0.2 s: the chain is stuck -- report, do not hang
+                    if (lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+    }
+    MERV_DEVICE u32x4 load16(const bf16_t* base, int elem, int total_elems) const {
+#ifdef MERV_CHAIN_ABL_PLAINX  // ablation (stale reads possible): the input vector through L1 like the stand-alone kernels
+        return *(const u32x4*)(base + elem);
+#endif
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, total_elems * 2, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, elem * 2, 0, 16);  // aux 16 = sc1
+    }
+    MERV_DEVICE float load_bf16(const bf16_t* base, int elem, int total_elems) const {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, total_elems * 2, 0x00020000);
+        return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, elem * 2, 0, 16));
+    }
+    // by the ONE lane that stored this workgroup's outputs, right after those stores
+    MERV_DEVICE void signal() const {
+        if (mine == nullptr) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(mine + (block & (CHAIN_SHARDS - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+MERV_DEVICE void store_sc1_u64(void* ptr, unsigned long long v) {
+    __hip_atomic_store((unsigned long long*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- GEMV: W [N, K] bf16 row-major streamed once; each wave owns ROWS output rows, lanes stride K in 16-byte chunks ----
 constexpr int GEMV_WAVES = 4;  // waves per block
+struct GemvLds {
+    float norm_part[GEMV_WAVES];
+    bf16_t out_stage[GEMV_WAVES * 2];  // chained launches: the block's outputs, stored by one lane
+};
 
 // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in; GEMV_ROWS: output rows per wave (the x chunk
-// is reused across them)
-template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
-__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
+// is reused across them). `block`: this workgroup's index within the operation. Chained: every row count is a multiple of
+// GEMV_WAVES * GEMV_ROWS (no idle waves, a block's rows lie in one matrix) and the outputs are bf16 (the logits' consumer is
+// the host).
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS, class HO>
+MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, const HO& ho) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
-    int n0 = (blockIdx.x * GEMV_WAVES + wave) * GEMV_ROWS;
+    int n0 = (block * GEMV_WAVES + wave) * GEMV_ROWS;
     // several matrices in one launch (q / k / v): a wave's rows lie in ONE of them (row counts are multiples of GEMV_ROWS)
     if constexpr (NW_MATS == 1) {
         if (n0 >= p.N && p.Nb > 0) {
@@ -80,7 +186,10 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
             else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; p.bias = p.bias_c; }
         }
     }
-    if (n0 >= p.N) return;
+    static_assert(GEMV_WAVES == 4, "the fused norm splits the row's sum of squares over the block's four waves");
+    // a wave past the last row still takes part in the fused norm's block-wide reduction (and then leaves)
+    const bool idle = n0 >= p.N;
+    if (idle && !NORM && !HO::chained) return;
     const int nchunk = p.K >> 3;
     float acc[NW_MATS][GEMV_ROWS];
 #pragma unroll
@@ -99,7 +208,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     // address and meet x = 0 (a remainder loop of single loads costs one memory round trip per iteration: 3 us of the
     // K = 11008 launch).
     u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[NORM ? UN : 1];
-    auto issue = [&](int c) {
+    auto issue_w = [&](int c) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
@@ -107,24 +216,48 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
             for (int m = 0; m < NW_MATS; ++m)
 #pragma unroll
                 for (int r = 0; r < GEMV_ROWS; ++r) wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + cu * 8));
-            xv[u] = *(const u32x4*)(p.x + cu * 8);
+        }
+    };
+    auto issue_x = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+            xv[u] = ho.load16(p.x, cu * 8, p.K);
             if constexpr (NORM) nv[u] = *(const u32x4*)(p.norm_w + cu * 8);
         }
     };
-    // fused RMSNorm: the wave reduces mean(x^2) over the whole input once (8 KB, L2-resident) BEHIND the first trip's weight
-    // loads, then normalises each chunk it multiplies
+    // fused RMSNorm: the BLOCK reduces mean(x^2) over the whole input once (8 KB, L2-resident; a quarter per wave) and every wave
+    // normalises the chunks it multiplies. Stand-alone: the norm's chunks are requested FIRST (vmcnt is in order: they return
+    // first) and the whole first trip before anything waits for them. Chained: the first trip's WEIGHTS are requested before the
+    // wait for the producer -- that is what keeps the HBM stream going across operations -- and everything that reads x after it.
     int c = lane;
-    if (c < nchunk) issue(c);
+    u32x4 nx[4];
+    if constexpr (HO::chained) {
+        issue_w(c);
+        ho.wait_input(wave);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cc = lane + 64 * wave + 256 * i;
+                nx[i] = cc < nchunk ? ho.load16(p.x, cc * 8, p.K) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        issue_x(c);
+    } else {
+        if constexpr (NORM) sumsq_request(p.x, nchunk, lane, wave, nx);
+        // unconditional (idle waves of the last block re-read a valid row; K >= 512, so lane < nchunk): behind a branch hipcc's
+        // waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip behind them
+        issue_w(c);
+        issue_x(c);
+        __builtin_amdgcn_sched_barrier(0);  // the whole first trip is requested before anything waits for the norm's chunks
+    }
     float rstd = 0.f;
     if constexpr (NORM) {
-        float ss = 0.f;
-        for (int cc = lane; cc < nchunk; cc += 64) {
-            float f[8];
-            unpack8f(*(const u32x4*)(p.x + cc * 8), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
-        }
-        rstd = rsqrtf(wave_sum64(ss) / (float)p.K + p.norm_eps);
+        const float part = sumsq_finish(p.x, nchunk, lane, wave, nx);  // (K <= 8192: no load inside)
+        if (lane == 0) lds.norm_part[wave] = part;
+        __syncthreads();
+        if (idle) return;
+        rstd = rsqrtf((((lds.norm_part[0] + lds.norm_part[1]) + lds.norm_part[2]) + lds.norm_part[3]) / (float)p.K + p.norm_eps);
     }
     for (; c < nchunk; c += 64 * UN) {
 #pragma unroll
@@ -151,7 +284,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
                     for (int j = 0; j < 8; ++j) acc[m][r] = fmaf(wf[j], xf[j], acc[m][r]);
                 }
         }
-        if (c + 64 * UN < nchunk) issue(c + 64 * UN);
+        if (c + 64 * UN < nchunk) { issue_w(c + 64 * UN); issue_x(c + 64 * UN); }
     }
 #pragma unroll
     for (int m = 0; m < NW_MATS; ++m)
@@ -168,12 +301,34 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
                 const float s = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor
                 v = s * round_bf(acc[1][r]);
             } else if (p.res) {
-                v = v + bf2f(p.res[n]);  // x + linear(...), rounded once more below
+                v = v + ho.load_bf16(p.res, n, p.N);  // x + linear(...), rounded once more below
             }
             if (p.y32) p.y32[n] = v;  // logits: .float() of the bf16 linear output
+            else if constexpr (HO::chained) lds.out_stage[wave * GEMV_ROWS + r] = f2bf(v);
             else p.y[n] = f2bf(v);
         }
     }
+    if constexpr (HO::chained) {
+        if (p.y32) return;  // (uniform) the host reads the logits after the launch
+        __syncthreads();
+        if (threadIdx.x == 0) {  // the block's GEMV_WAVES * GEMV_ROWS consecutive outputs: 8 bytes per store, write-through
+            bf16_t* dst = p.y + n0;  // thread 0 is in wave 0: n0 is the block's first row (in its own matrix)
+#pragma unroll
+            for (int q = 0; q < GEMV_WAVES * GEMV_ROWS / 4; ++q) {
+                unsigned long long w = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w |= (unsigned long long)lds.out_stage[4 * q + j] << (16 * j);
+                store_sc1_u64(dst + 4 * q, w);
+            }
+            ho.signal();
+        }
+    }
+}
+
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
+__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
+    __shared__ GemvLds lds;
+    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds, NoHandoff{});
 }
 
 // ---- rotary embedding of q and k at the current position + cache update ----
@@ -342,11 +497,16 @@ __global__ __launch_bounds__(128) void decode_attn_merge_kernel(DecodeAttnArgs p
 // 16 / 32 splits, 16.5 with one 1024-thread block per head and no workspace round trip, 12.5-13.8 with 1024-thread blocks
 // and 2-8 splits -- the launch is a chain of dependent memory round trips (position -> tables / q / cache rows -> partials ->
 // ticket -> partials), not a bandwidth problem (17 MB of cache).
-__global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAttnFusedArgs p) {
-    __shared__ float sm_m[16], sm_l[16];
-    __shared__ __attribute__((aligned(16))) float sm_o[16][128];
-    __shared__ unsigned sm_ticket;
-    const int h = blockIdx.x, s = blockIdx.y;
+struct AttnLds {
+    float m[16], l[16];
+    __attribute__((aligned(16))) float o[16][128];
+    unsigned ticket;
+};
+// h: head, s: position range. Chained: q / k / v are the q / k / v operation's outputs (sc1 loads behind the wait), the merged
+// head goes out as 4-byte write-through stores and EVERY block adds to the operation's counter when it is done -- the merging
+// block of a head after its output stores, so H * nsplit arrivals mean every head is merged.
+template <class HO>
+MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, const int s, AttnLds& lds, const HO& ho) {
     const int grp_heads = p.H / p.Hkv;
     const int hkv = h / grp_heads;
     const long pos = *p.pos;
@@ -360,8 +520,9 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
     float cf[8], sf[8];
     unpack8f(*(const u32x4*)(p.cos + pos * 128 + sub * 8), cf);
     unpack8f(*(const u32x4*)(p.sin + pos * 128 + sub * 8), sf);
-    auto rotary = [&](const bf16_t* vec, float (&r)[8]) {
-        const u32x4 own = *(const u32x4*)(vec + sub * 8);
+    ho.wait_input(__builtin_amdgcn_readfirstlane(wave));
+    auto rotary = [&](const bf16_t* base, int off, int total, float (&r)[8]) {
+        const u32x4 own = ho.load16(base, off + sub * 8, total);
         u32x4 oth;
 #pragma unroll
         for (int q = 0; q < 4; ++q) oth[q] = __shfl_xor(own[q], 8, 64);
@@ -373,7 +534,7 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
         for (int i = 0; i < 8; ++i) r[i] = round_bf(round_bf(a[i] * cf[i]) + round_bf(sgn * b[i] * sf[i]));
     };
     float qf[8];
-    rotary(p.q + h * 128, qf);
+    rotary(p.q, h * 128, p.H * 128, qf);
     bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
     bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
     DaState st;
@@ -384,8 +545,8 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
     da_range(st, qf, Kc, Vc, j0, j1 < pos ? j1 : (int)pos, g, sub, sc);  // cached positions of this range end before the current token
     if (pos >= j0 && pos < j1 && g == (int)((pos - j0) & 15)) {  // uniform per 16-lane group: the shuffles inside stay in the group
         float kf[8], vf[8];
-        rotary(p.k + hkv * 128, kf);
-        const u32x4 vraw = *(const u32x4*)(p.v + hkv * 128 + sub * 8);
+        rotary(p.k, hkv * 128, p.Hkv * 128, kf);
+        const u32x4 vraw = ho.load16(p.v, hkv * 128 + sub * 8, p.Hkv * 128);
         unpack8f(vraw, vf);
         da_one(st, qf, kf, vf, sc);
         if (h % grp_heads == 0) {
@@ -396,22 +557,22 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
             *(u32x4*)(Vc + (size_t)pos * 128 + sub * 8) = vraw;
         }
     }
-    if (sub == 0) { sm_m[g] = st.m; sm_l[g] = st.l; }
+    if (sub == 0) { lds.m[g] = st.m; lds.l[g] = st.l; }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sm_o[g][sub * 8 + i] = st.o[i];
+    for (int i = 0; i < 8; ++i) lds.o[g][sub * 8 + i] = st.o[i];
     __syncthreads();
     float* ws_h = p.ws + (size_t)h * p.nsplit * (128 + 2);
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
         float M = -INFINITY;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) M = fmaxf(M, sm_m[q]);
+        for (int q = 0; q < 16; ++q) M = fmaxf(M, lds.m[q]);
         float L = 0.f, O = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float w = sm_m[q] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(sm_m[q] - M);
-            L = fmaf(w, sm_l[q], L);
-            O = fmaf(w, sm_o[q][d], O);
+            const float w = lds.m[q] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(lds.m[q] - M);
+            L = fmaf(w, lds.l[q], L);
+            O = fmaf(w, lds.o[q][d], O);
         }
         // the partials travel between blocks (possibly between XCDs, each with its own L2) inside one launch: device-scope
         // relaxed atomics write through / read past the non-coherent cache levels, which costs nothing beside an ordinary
@@ -424,18 +585,24 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
         }
     }
     // publish (every store of this block acknowledged), then take a ticket; the last arrival of this head merges.
-    // This is the write-through form of the in-launch hand-off (cdna_hip_programming.md section 5, "Projection GEMM at M = 256"
-    // item 2, "Equally valid": sc1 slab stores -> every wave vmcnt(0) -> __syncthreads -> relaxed agent-scope fetch_add; the
-    // reducer reads the slabs with sc1 loads, EVERY load of them): relaxed agent-scope atomic stores / loads ARE the sc1 forms,
-    // so no release / acquire fence pair is needed and none is paid for (+15 us per layer when tried). Two invariants carry it:
-    // (1) every partial is written and read ONLY through these atomics, (2) one workspace serves one stream -- launches that
-    // share it must not overlap (HipDecoder owns one per decoder and zeroes it in prefill()).
-    __builtin_amdgcn_s_waitcnt(0);
+    // This is the write-through form of the in-launch hand-off (cdna_hip_programming.md Guideline 16, R1 in its counter form, and
+    // MI355X_MICROARCH.md "Valid forms", first table row): every partial is stored sc1 (relaxed agent-scope atomic stores ARE
+    // global_store ... sc1), every storing wave waits vmcnt(0) -- as ASM: hipcc can drop a builtin wait it believes redundant
+    // (Guideline 16, Pitfall 12) -- the workgroup meets at its barrier, ONE lane adds to the head's counter (agent-scope atomic),
+    // and the merging workgroup -- the one whose add returned nsplit - 1, told to its other waves through LDS behind a barrier --
+    // reads every partial with sc1 loads (relaxed agent-scope atomic loads). No release / acquire fence is needed in this form and
+    // none is paid for (a fence pair cost +15 us per layer). Invariants: (1) every partial is written and read ONLY through these
+    // atomics, (2) one workspace serves one stream -- launches that share it must not overlap (HipDecoder owns one per decoder and
+    // zeroes it in prefill()). tools/probes/decode_attention_stress.py hammers it under uneven load.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned* counter = (unsigned*)(p.ws + (size_t)p.H * p.nsplit * (128 + 2)) + h * 32;  // one 128-byte line per head
-    if (threadIdx.x == 0) sm_ticket = atomicAdd(counter, 1u);
+    if (threadIdx.x == 0) lds.ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (sm_ticket != (unsigned)(p.nsplit - 1)) return;
+    if (lds.ticket != (unsigned)(p.nsplit - 1)) {
+        if (threadIdx.x == 0) ho.signal();  // (chained) done, nothing more to publish
+        return;
+    }
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
         auto ld = [&](int i) { return __hip_atomic_load(ws_h + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -448,9 +615,105 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
             L = fmaf(w, ld(q * 130 + 129), L);
             O = fmaf(w, ld(q * 130 + d), O);
         }
-        p.out[h * 128 + d] = f2bf(O / L);
+        const bf16_t ob = f2bf(O / L);
+        if constexpr (HO::chained) {  // pairs of dims as one 4-byte write-through store
+            const unsigned hi = __shfl_down((unsigned)ob, 1, 64);
+            if ((d & 1) == 0)
+                __hip_atomic_store((unsigned*)(p.out + h * 128 + d), (unsigned)ob | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            p.out[h * 128 + d] = ob;
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (HO::chained) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave (waves 0 and 1), then ONE lane signals
+        __syncthreads();
+        if (threadIdx.x == 0) ho.signal();
+    }
+}
+
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAttnFusedArgs p) {
+    __shared__ AttnLds lds;
+    attn_fused_body(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The whole decode step as ONE launch (round 4). Five launches per layer each cost ~2.5 us of boundary, ramp and drain beside
+// their HBM stream (t = 2.5 us + bytes / 5.9 TB/s fits all four GEMV classes) and the attention launch is a 14 us latency chain
+// over 17 MB. Here the operations of all layers (and the lm_head) are block ranges of one grid, in dependency order. The
+// hardware hands out workgroups in index order, so when the last blocks of an operation are running, the blocks of the next one
+// are already resident behind them: they have requested their first weights (everything a block needs besides the producer's
+// output vector) and wait on the producer's arrival counter -- the HBM stream does not stop at an operation boundary.
+// Progress: every block waits only on blocks of LOWER index, and the lowest-index unfinished block of the grid is resident
+// (in-order dispatch per XCD), so it can always run; if that premise ever failed, the bounded spin reports through *err.
+// Arithmetic, rounding points and reduction orders are those of the separate kernels (same body functions): bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+// (chunks per lane and trip, rows per wave) of each operation's blocks; a row's accumulation order does not depend on them
+#ifndef MERV_CHAIN_CFG
+#define MERV_CHAIN_CFG 4, 2, 4, 2, 4, 1, 4, 2
+#endif
+constexpr int CHAIN_CFG[8] = {MERV_CHAIN_CFG};  // qkv + lm_head, o_proj, gate / up, down_proj
+constexpr int CQ_UN = CHAIN_CFG[0], CQ_ROWS = CHAIN_CFG[1], CO_UN = CHAIN_CFG[2], CO_ROWS = CHAIN_CFG[3];
+constexpr int CG_UN = CHAIN_CFG[4], CG_ROWS = CHAIN_CFG[5], CD_UN = CHAIN_CFG[6], CD_ROWS = CHAIN_CFG[7];
+
+__global__ __launch_bounds__(DA_THREADS) void decode_chain_kernel(DecodeChainArgs c) {
+    static_assert(DA_THREADS == GEMV_WAVES * 64, "one block shape for every operation");
+    __shared__ union { GemvLds g; AttnLds a; } lds;
+    const int bpl = c.nb_qkv + c.nb_attn + c.nb_o + c.nb_gu + c.nb_down;
+    const int bid = blockIdx.x;
+    const int layer = bid / bpl;  // == c.L: the lm_head
+    int r = bid - layer * bpl;
+    auto counter = [&](int op) { return c.counters + (size_t)op * CHAIN_OP_STRIDE; };
+    ChainHandoff ho;
+    ho.err = c.err;
+    const int HD = c.H * 128, KVD = c.Hkv * 128;
+    if (layer >= c.L) {  // final norm + lm_head -> fp32 logits
+        ho.block = r; ho.dep = counter(c.L * 5 - 1); ho.expected = c.nb_down; ho.mine = nullptr;
+        DecodeGemvArgs g{};
+        g.W = c.lm_head; g.x = c.x; g.y32 = c.logits; g.N = c.V; g.K = c.D; g.norm_w = c.final_norm; g.norm_eps = c.eps;
+        gemv_body<1, CQ_UN, true, CQ_ROWS>(g, r, lds.g, ho);
+        return;
+    }
+    const DecodeLayerW& w = c.layers[layer];
+    const int op0 = layer * 5;
+    if (r < c.nb_qkv) {  // input_layernorm + q / k / v projections
+        ho.block = r; ho.dep = layer > 0 ? counter(op0 - 1) : nullptr; ho.expected = c.nb_down; ho.mine = counter(op0);
+        DecodeGemvArgs g{};
+        g.W = w.wq; g.Wb = w.wk; g.Wc = w.wv; g.x = c.x; g.y = c.q; g.yb = c.k; g.yc = c.v; g.N = HD; g.Nb = KVD; g.Nc = KVD; g.K = c.D;
+        g.norm_w = w.ln1; g.norm_eps = c.eps; g.bias = w.bq; g.bias_b = w.bk; g.bias_c = w.bv;
+        gemv_body<1, CQ_UN, true, CQ_ROWS>(g, r, lds.g, ho);
+        return;
+    }
+    r -= c.nb_qkv;
+    if (r < c.nb_attn) {  // rotary + cache update + split attention + merge
+        ho.block = r; ho.dep = counter(op0); ho.expected = c.nb_qkv; ho.mine = counter(op0 + 1);
+        DecodeAttnFusedArgs a{c.q, c.k, c.v, c.cos, c.sin, w.kc, w.vc, c.ao, c.attn_ws, c.pos, c.H, c.Hkv, 128, c.max_len, c.nsplit, c.scale};
+        attn_fused_body(a, r % c.H, r / c.H, lds.a, ho);
+        return;
+    }
+    r -= c.nb_attn;
+    if (r < c.nb_o) {  // x += o_proj(attention)
+        ho.block = r; ho.dep = counter(op0 + 1); ho.expected = c.nb_attn; ho.mine = counter(op0 + 2);
+        DecodeGemvArgs g{};
+        g.W = w.wo; g.x = c.ao; g.res = c.x; g.y = c.x; g.N = c.D; g.K = HD;
+        gemv_body<1, CO_UN, false, CO_ROWS>(g, r, lds.g, ho);
+        return;
+    }
+    r -= c.nb_o;
+    if (r < c.nb_gu) {  // post_attention_layernorm + silu(gate) * up
+        ho.block = r; ho.dep = counter(op0 + 2); ho.expected = c.nb_o; ho.mine = counter(op0 + 3);
+        DecodeGemvArgs g{};
+        g.W = w.wg; g.W2 = w.wu; g.x = c.x; g.y = c.mid; g.N = c.I; g.K = c.D; g.norm_w = w.ln2; g.norm_eps = c.eps;
+        gemv_body<2, CG_UN, true, CG_ROWS>(g, r, lds.g, ho);
+        return;
+    }
+    r -= c.nb_gu;
+    {   // x += down_proj(mid)
+        ho.block = r; ho.dep = counter(op0 + 3); ho.expected = c.nb_gu; ho.mine = counter(op0 + 4);
+        DecodeGemvArgs g{};
+        g.W = w.wd; g.x = c.mid; g.res = c.x; g.y = c.x; g.N = c.D; g.K = c.I;
+        gemv_body<1, CD_UN, false, CD_ROWS>(g, r, lds.g, ho);
+    }
 }
 
 }  // namespace
@@ -519,6 +782,24 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+size_t decode_chain_counter_bytes(int layers) { return (size_t)(layers * 5 + 1) * CHAIN_OP_STRIDE * sizeof(unsigned); }
+
+// Every row count must fill whole blocks of its operation (GEMV_WAVES x rows-per-wave rows: CHAIN_CFG).
+hipError_t launch_decode_chain(const DecodeChainArgs& a_in, hipStream_t s) {
+    DecodeChainArgs a = a_in;
+    if (a.L <= 0 || a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
+    const int HD = a.H * 128, KVD = a.Hkv * 128;
+    const int rq = GEMV_WAVES * CQ_ROWS, ro = GEMV_WAVES * CO_ROWS, rg = GEMV_WAVES * CG_ROWS, rd = GEMV_WAVES * CD_ROWS;
+    if (HD % rq || KVD % rq || a.V % rq || a.D % ro || a.I % rg || a.D % rd || a.D % 8 || a.I % 8 || a.D < 512 || a.D > 8192 || a.I < 512)
+        return hipErrorInvalidValue;
+    a.nb_qkv = (HD + 2 * KVD) / rq; a.nb_attn = a.H * a.nsplit; a.nb_o = a.D / ro; a.nb_gu = a.I / rg; a.nb_down = a.D / rd;
+    a.nb_head = a.V / rq;
+    if (hipError_t e = hipMemsetAsync(a.counters, 0, decode_chain_counter_bytes(a.L), s); e != hipSuccess) return e;
+    const long blocks = (long)a.L * (a.nb_qkv + a.nb_attn + a.nb_o + a.nb_gu + a.nb_down) + a.nb_head;
+    hipLaunchKernelGGL(decode_chain_kernel, dim3((unsigned)blocks), dim3(DA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

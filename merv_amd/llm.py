@@ -11,6 +11,7 @@ llama2.py:74-76), or loads a local state dict.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -156,6 +157,7 @@ class LlamaBackbone:
         top_p = 1.0 if top_p is None else float(top_p)
         repetition_penalty = 1.0 if repetition_penalty is None else float(repetition_penalty)
         top_k = int(top_k or 0)
+        dec = None
         if use_graph and self._needs_hf_decode(inputs_embeds.shape[1] + max_new_tokens + 1):
             use_graph = False  # the static-cache decoders implement neither sliding-window attention nor MLP biases
         if use_graph and inputs_embeds.is_cuda and inputs_embeds.shape[1] + max_new_tokens + 1 <= self.config.max_position_embeddings:
@@ -213,6 +215,8 @@ class LlamaBackbone:
             if i + 1 < max_new_tokens:
                 logits = step(nxt)
         ids = torch.stack(new_tokens, 1)
+        if hasattr(dec, "check_chain"):
+            dec.check_chain()  # the one-launch decode step reports a stuck hand-off instead of hanging: fail loudly
         if eos_token_id is not None:  # the EOS test above runs every 8 tokens: cut at the step where every row had finished
             all_done = ((ids == eos_token_id).cumsum(1) > 0).all(0)
             if bool(all_done.any()):
@@ -374,6 +378,50 @@ class HipDecoder(StaticDecoder):
         # partials of the split attention + one arrival counter per head (zero between launches: the kernel restores them)
         self.ws = torch.zeros(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT), dtype=torch.float32, device=self.dev)
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
+        self.chain = None  # built at the first step (the position tensor it points to is created by prefill())
+        self._want_chain = self.use_chain and self.chain_supported(hf_model)
+
+    # The whole step as ONE launch (csrc/decode.hip, decode_chain_kernel): default; MERV_DECODE_CHAIN=0 keeps the 5 launches per layer
+    use_chain = os.environ.get("MERV_DECODE_CHAIN", "1") != "0"
+
+    @staticmethod
+    def chain_supported(hf_model) -> bool:
+        cfg = hf_model.config
+        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        kvd = getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) * hd
+        return (hd == 128 and cfg.hidden_size % 8 == 0 and 512 <= cfg.hidden_size <= 8192 and cfg.intermediate_size % 8 == 0 and
+                cfg.intermediate_size >= 512 and cfg.vocab_size % 8 == 0 and kvd % 8 == 0)
+
+    def _build_chain(self):
+        from ._lib import DECODE_LAYER_FIELDS, DecodeChain, ptr
+        m, cfg = self.m, self.cfg
+        rows = []
+        for li, lyr in enumerate(m.model.layers):
+            a, mlp = lyr.self_attn, lyr.mlp
+            bias = lambda lin: 0 if lin.bias is None else ptr(lin.bias)
+            e = dict(wq=ptr(a.q_proj.weight), wk=ptr(a.k_proj.weight), wv=ptr(a.v_proj.weight), wo=ptr(a.o_proj.weight),
+                     wg=ptr(mlp.gate_proj.weight), wu=ptr(mlp.up_proj.weight), wd=ptr(mlp.down_proj.weight),
+                     ln1=ptr(lyr.input_layernorm.weight), ln2=ptr(lyr.post_attention_layernorm.weight),
+                     bq=bias(a.q_proj), bk=bias(a.k_proj), bv=bias(a.v_proj), k_cache=ptr(self.K[li]), v_cache=ptr(self.V[li]))
+            rows.append([e[f] for f in DECODE_LAYER_FIELDS])
+        self._chain_layers = torch.tensor(rows, dtype=torch.int64, device=self.dev)  # the device table of merv_decode_layer entries
+        self._chain_counters = torch.zeros(self.lib.merv_decode_chain_counter_bytes(len(rows)) // 4, dtype=torch.int32, device=self.dev)
+        self.chain_err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        c = DecodeChain()
+        c.layers = ptr(self._chain_layers)
+        c.L, c.D, c.I, c.H, c.Hkv, c.hd, c.V = len(rows), cfg.hidden_size, cfg.intermediate_size, self.H, self.Hkv, self.hd, cfg.vocab_size
+        c.max_len, c.nsplit = self.max_len, self.NSPLIT
+        c.x, c.q, c.k, c.v, c.ao, c.mid = ptr(self.x), ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.ao), ptr(self.mid)
+        c.logits, c.cos_t, c.sin_t, c.pos, c.attn_ws = ptr(self.logits32), ptr(self.cos), ptr(self.sin), ptr(self.pos), ptr(self.ws)
+        c.final_norm, c.lm_head = ptr(m.model.norm.weight), ptr(m.lm_head.weight)
+        c.counters, c.err = ptr(self._chain_counters), ptr(self.chain_err)
+        c.eps, c.scale = self.eps, self.hd**-0.5
+        return c
+
+    def check_chain(self) -> None:
+        """Raises if a wait inside a chained step ever gave up (one host read; generate() calls it once per generation)."""
+        if self.chain is not None and int(self.chain_err.item()) != 0:
+            raise RuntimeError("merv_decode_chain_step: a hand-off wait timed out inside the decode launch (results invalid)")
 
     def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         # the fused attention launch expects its per-head arrival counters at zero and restores them itself; an aborted launch
@@ -389,6 +437,12 @@ class HipDecoder(StaticDecoder):
             st = torch.cuda.current_stream(self.dev).cuda_stream
             D, I, H, Hkv, hd = self.cfg.hidden_size, self.cfg.intermediate_size, self.H, self.Hkv, self.hd
             self.x.copy_(m.model.embed_tokens(self.tok).reshape(-1))
+            if self._want_chain and self.chain is None:
+                self.chain = self._build_chain()
+            if self.chain is not None:
+                import ctypes
+                check(lib.merv_decode_chain_step(ctypes.addressof(self.chain), st), "merv_decode_chain_step")
+                return self.logits32
             x, h, pos = ptr(self.x), ptr(self.h), ptr(self.pos)
 
             def gemv(W, W2, xin, res, y, N, K, y32=0, norm=None):
