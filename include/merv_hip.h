@@ -349,6 +349,17 @@ size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
+/* merv_decode_attention_fused and the o-projection with its residual, x[D] += Wo[D, H*hd] . attention, as ONE launch (bit-identical
+ * to the two calls): one workgroup per (head, position range) whose second half -- four loader waves -- brings its 16 rows of Wo into
+ * LDS while the first half runs the attention, so the o-projection's weight stream hides under the attention's latency chain. `out`
+ * still receives the attention output. Requires D == 16 * H * nsplit (nsplit = 8 for hd = 128) and H * hd <= 4608.
+ * counters: merv_decode_attn_oproj_counter_bytes() bytes of device memory (zero before the first call; every launch restores them);
+ * err: one device word, OR-ed when an in-launch wait gives up after 0.2 s (results invalid). */
+size_t merv_decode_attn_oproj_counter_bytes(void);
+int merv_decode_attn_oproj(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
+                           void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
+                           int32_t nsplit, float scale, const void *Wo, void *x, int32_t D, void *counters, uint32_t *err, void *stream);
+
 /*
  * The whole decode step -- every layer's five operations and the final norm + lm_head -- as ONE launch (round 4): the operations are
  * block ranges of one grid in dependency order; a block requests its first weights, then waits on its producer's arrival counter

@@ -864,6 +864,27 @@ extern "C" int merv_decode_attention_fused(const void* q, const void* k, const v
     return 0;
 }
 
+extern "C" size_t merv_decode_attn_oproj_counter_bytes(void) { return decode_attn_oproj_counter_bytes(); }
+
+extern "C" int merv_decode_attn_oproj(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t, const int64_t* pos,
+                                      void* k_cache, void* v_cache, void* out, float* ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
+                                      int32_t nsplit, float scale, const void* Wo, void* x, int32_t D, void* counters, uint32_t* err,
+                                      void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && cos_t && sin_t && pos && k_cache && v_cache && out && ws && Wo && x && counters && err,
+               "merv_decode_attn_oproj: null argument");
+    MERV_CHECK(hd == 128, "merv_decode_attn_oproj: head_dim must be 128");
+    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attn_oproj: bad geometry");
+    MERV_CHECK(D == 16 * H * nsplit && (H * hd) % 512 == 0 && H * hd <= 4608,
+               "merv_decode_attn_oproj: needs D == 16 * H * nsplit and H * hd a multiple of 512, at most 4608");
+    DecodeAttnOprojArgs a{};
+    a.a = DecodeAttnFusedArgs{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
+                              (bf16_t*)v_cache, (bf16_t*)out, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale};
+    a.Wo = (const bf16_t*)Wo; a.x = (bf16_t*)x; a.D = D; a.counters = (unsigned*)counters; a.err = err;
+    MERV_HIP(launch_decode_attn_oproj(a, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" size_t merv_decode_chain_counter_bytes(int32_t layers) { return layers > 0 ? decode_chain_counter_bytes(layers) : 0; }
 
 extern "C" int merv_decode_chain_step(const merv_decode_chain* c, void* stream_) {

@@ -209,6 +209,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
     // K = 11008 launch).
     u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[NORM ? UN : 1];
     auto issue_w = [&](int c) {
+        c = c < nchunk ? c : 0;  // (rows shorter than 64 chunks: the lanes past the end load a valid chunk and multiply nothing)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
@@ -219,6 +220,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
         }
     };
     auto issue_x = [&](int c) {
+        c = c < nchunk ? c : 0;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
@@ -245,8 +247,8 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
         issue_x(c);
     } else {
         if constexpr (NORM) sumsq_request(p.x, nchunk, lane, wave, nx);
-        // unconditional (idle waves of the last block re-read a valid row; K >= 512, so lane < nchunk): behind a branch hipcc's
-        // waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip behind them
+        // unconditional (idle waves of the last block re-read a valid row, lanes past a short row's end a valid chunk): behind a
+        // branch hipcc's waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip
         issue_w(c);
         issue_x(c);
         __builtin_amdgcn_sched_barrier(0);  // the whole first trip is requested before anything waits for the norm's chunks
@@ -638,6 +640,91 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Attention + o-projection as ONE launch (round 4). The attention launch is a 14 us chain of dependent memory round trips over
+// 17 MB of cache -- the HBM pipe idles -- and the o-projection behind it streams 33.5 MB in 8 us. Here every workgroup (one per
+// CU: head h, position range s, as in the fused attention launch) has a second half of four LOADER waves that bring the
+// workgroup's 16 rows of W_o into LDS by LDS-DMA (128 KB per CU at D = 4096: the whole matrix sits in the chip's LDS) while
+// waves 0-3 run the attention; the attention outputs are handed over in-launch (write-through stores + arrival counter, as in
+// the chain kernel below), and all eight waves finish x += W_o . attention from LDS. The weight stream costs no time of its own.
+// vmcnt is one in-order counter per wave, so the DMA cannot ride in the attention waves (every attention load would wait for
+// the DMAs queued before it): hence the loader waves; they mirror the attention body's workgroup barriers.
+// Counters (per layer): the arrival shards and a departure word; the workgroup that leaves last (every workgroup has passed the
+// wait by then) zeroes them, so the launch leaves its counters as it found them and a captured graph replays at any position.
+// Same arithmetic and reduction order as the separate launches: bit-identical.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AO_ROWS = 16;  // W_o rows per workgroup
+__global__ __launch_bounds__(512) void decode_attn_oproj_kernel(DecodeAttnOprojArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char wbuf[];  // [AO_ROWS][K] bf16, lane-linear 1-KiB pieces
+    __shared__ AttnLds alds;
+    __shared__ bf16_t out16[AO_ROWS];
+    const int bid = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int K = p.a.H * 128, npc = K >> 9;  // 512-element pieces per row
+    const int nblocks = p.a.H * p.a.nsplit;
+    unsigned* cnt = p.counters;                          // arrival shards
+    unsigned* departed = p.counters + CHAIN_OP_STRIDE;   // workgroups that are past the wait and done
+    if (wave >= 4) {  // loader waves: rows 4 (wave - 4) .. + 3 of the workgroup's 16
+        const int r0 = 4 * (wave - 4);
+        for (int r = r0; r < r0 + 4; ++r) {
+            const bf16_t* src = p.Wo + (size_t)(bid * AO_ROWS + r) * K + lane * 8;
+            for (int pc = 0; pc < npc; ++pc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 512),
+                                                 (__attribute__((address_space(3))) void*)(wbuf + ((size_t)r * K + pc * 512) * 2), 16, 0, 0);
+        }
+        // the attention body's three workgroup barriers (a fourth in the head's merging workgroup): raw, nothing to wait for yet
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");  // (the ticket was written before the third barrier: do not read it earlier)
+        if (*(volatile unsigned*)&alds.ticket == (unsigned)(p.a.nsplit - 1)) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have landed (before the barrier inside wait_input)
+    } else {
+        ChainHandoff ho;
+        ho.dep = nullptr; ho.expected = 0; ho.mine = cnt; ho.err = p.err; ho.block = bid;
+        attn_fused_body(p.a, bid % p.a.H, bid / p.a.H, alds, ho);
+    }
+    ChainHandoff hw;
+    hw.dep = cnt; hw.expected = (unsigned)nblocks; hw.mine = nullptr; hw.err = p.err; hw.block = bid;
+    hw.wait_input(wave);  // every head is merged and published; (barrier inside) every loader wave's rows are in LDS
+    // x[n] += W_o[n, :] . attention, rows 16 bid + 2 wave, + 1: chunks lane, lane + 64, ... in order, as gemv_body
+    float acc[2] = {0.f, 0.f};
+    for (int pc = 0; pc < npc; ++pc) {
+        float xf[8];
+        unpack8f(hw.load16(p.a.out, (pc * 64 + lane) * 8, K), xf);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float wf[8];
+            unpack8f(*(const u32x4*)(wbuf + ((size_t)(2 * wave + r) * K + pc * 512) * 2 + lane * 16), wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wf[j], xf[j], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) acc[r] = wave_sum64(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int n = bid * AO_ROWS + 2 * wave + r;
+            const float v = round_bf(acc[r]) + hw.load_bf16(p.x, n, nblocks * AO_ROWS);  // x + linear(...), rounded once more
+            out16[2 * wave + r] = f2bf(v);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < AO_ROWS / 4) {  // 8 bytes per lane: the next launch reads x after this one has ended
+        unsigned long long w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w |= (unsigned long long)out16[4 * threadIdx.x + j] << (16 * j);
+        *(unsigned long long*)(p.x + bid * AO_ROWS + 4 * threadIdx.x) = w;
+    }
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1)) {
+#pragma unroll
+        for (int i = 0; i < CHAIN_SHARDS; ++i) __hip_atomic_store(cnt + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The whole decode step as ONE launch (round 4). Five launches per layer each cost ~2.5 us of boundary, ramp and drain beside
 // their HBM stream (t = 2.5 us + bytes / 5.9 TB/s fits all four GEMV classes) and the attention launch is a 14 us latency chain
 // over 17 MB. Here the operations of all layers (and the lm_head) are block ranges of one grid, in dependency order. The
@@ -782,6 +869,25 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+size_t decode_attn_oproj_counter_bytes() { return 2 * CHAIN_OP_STRIDE * sizeof(unsigned); }
+
+hipError_t launch_decode_attn_oproj(const DecodeAttnOprojArgs& a, hipStream_t s) {
+    const int K = a.a.H * 128, nblocks = a.a.H * a.a.nsplit;
+    if (a.a.hd != 128 || a.a.H <= 0 || a.a.Hkv <= 0 || a.a.H % a.a.Hkv != 0 || a.a.nsplit <= 0 || K % 512 != 0) return hipErrorInvalidValue;
+    if (a.D != nblocks * AO_ROWS) return hipErrorInvalidValue;  // one workgroup per (head, range) takes 16 rows: D = 16 H nsplit
+    const int lds = AO_ROWS * K * 2;
+    if (lds > 148 * 1024) return hipErrorInvalidValue;  // + 8.4 KB of static LDS (attention partials) <= 160 KB
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        if (hipError_t e = hipFuncSetAttribute((const void*)decode_attn_oproj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(decode_attn_oproj_kernel, dim3(nblocks), dim3(512), lds, s, a);
     return hipGetLastError();
 }
 

@@ -361,6 +361,19 @@ struct DecodeAttnFusedArgs {  // rotary(q, k at *pos) + cache[*pos] <- k, v + sp
 };
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s);
 
+// merv_decode_attention_fused + the o-projection with its residual (x += W_o . attention) as ONE launch: the workgroups' loader
+// waves bring W_o into LDS while the attention runs (decode.hip, decode_attn_oproj_kernel). Requires D == 16 * H * nsplit.
+struct DecodeAttnOprojArgs {
+    DecodeAttnFusedArgs a;   // a.out: the attention output [H * hd] (still written: the o-projection's input)
+    const bf16_t* Wo;        // [D, H * hd]
+    bf16_t* x;               // [D] residual stream, updated in place
+    int D;
+    unsigned* counters;      // decode_attn_oproj_counter_bytes() bytes per layer, zeroed once per generation
+    unsigned* err;           // one word, OR-ed when a wait gives up
+};
+size_t decode_attn_oproj_counter_bytes();
+hipError_t launch_decode_attn_oproj(const DecodeAttnOprojArgs& a, hipStream_t s);
+
 // The whole batch-1 decode step (all layers + lm_head) as ONE launch: decode.hip, decode_chain_kernel.
 struct DecodeLayerW {  // device table, one entry per layer
     const bf16_t *wq, *wk, *wv, *wo, *wg, *wu, *wd;  // nn.Linear weights [out, in]

@@ -380,9 +380,17 @@ class HipDecoder(StaticDecoder):
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
         self.chain = None  # built at the first step (the position tensor it points to is created by prefill())
         self._want_chain = self.use_chain and self.chain_supported(hf_model)
+        # attention + o-projection as one launch (W_o rides into LDS under the attention chain): needs D == 16 * H * NSPLIT
+        self.fuse_ao = (self.use_attn_oproj and D == 16 * self.H * self.NSPLIT and (self.H * self.hd) % 512 == 0 and self.H * self.hd <= 4608)
+        nlay = cfg.num_hidden_layers
+        self.ao_stride = self.lib.merv_decode_attn_oproj_counter_bytes() // 4
+        self.ao_counters = torch.zeros(nlay * self.ao_stride, dtype=torch.int32, device=self.dev)
+        self.chain_err = torch.zeros(1, dtype=torch.int32, device=self.dev)
 
-    # The whole step as ONE launch (csrc/decode.hip, decode_chain_kernel): default; MERV_DECODE_CHAIN=0 keeps the 5 launches per layer
-    use_chain = os.environ.get("MERV_DECODE_CHAIN", "1") != "0"
+    # The whole step as ONE launch (csrc/decode.hip, decode_chain_kernel): bit-identical but measured slower than the launches
+    # (EXPERIMENTS.md section 5) -- opt-in, MERV_DECODE_CHAIN=1
+    use_chain = os.environ.get("MERV_DECODE_CHAIN", "0") == "1"
+    use_attn_oproj = os.environ.get("MERV_DECODE_ATTN_OPROJ", "1") != "0"
 
     @staticmethod
     def chain_supported(hf_model) -> bool:
@@ -406,7 +414,6 @@ class HipDecoder(StaticDecoder):
             rows.append([e[f] for f in DECODE_LAYER_FIELDS])
         self._chain_layers = torch.tensor(rows, dtype=torch.int64, device=self.dev)  # the device table of merv_decode_layer entries
         self._chain_counters = torch.zeros(self.lib.merv_decode_chain_counter_bytes(len(rows)) // 4, dtype=torch.int32, device=self.dev)
-        self.chain_err = torch.zeros(1, dtype=torch.int32, device=self.dev)
         c = DecodeChain()
         c.layers = ptr(self._chain_layers)
         c.L, c.D, c.I, c.H, c.Hkv, c.hd, c.V = len(rows), cfg.hidden_size, cfg.intermediate_size, self.H, self.Hkv, self.hd, cfg.vocab_size
@@ -420,14 +427,15 @@ class HipDecoder(StaticDecoder):
 
     def check_chain(self) -> None:
         """Raises if a wait inside a chained step ever gave up (one host read; generate() calls it once per generation)."""
-        if self.chain is not None and int(self.chain_err.item()) != 0:
-            raise RuntimeError("merv_decode_chain_step: a hand-off wait timed out inside the decode launch (results invalid)")
+        if int(self.chain_err.item()) != 0:
+            raise RuntimeError("HIP decode step: an in-launch hand-off wait timed out (results invalid)")
 
     def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         # the fused attention launch expects its per-head arrival counters at zero and restores them itself; an aborted launch
         # (a fault, a killed process sharing the buffer) would leave them non-zero and every later merge would misfire -- so every
         # generation starts from a zeroed workspace (one memset per generate(), nothing per token)
         self.ws.zero_()
+        self.ao_counters.zero_()  # the fused attention + o-projection launches restore their counters; an aborted one would not
         return super().prefill(inputs_embeds)
 
     def _step(self):
@@ -457,10 +465,16 @@ class HipDecoder(StaticDecoder):
                                                  ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps,
                                                  0 if bq is None else ptr(bq), 0 if bk is None else ptr(bk), 0 if bv is None else ptr(bv), st),
                       "merv_decode_gemv3_bias")
-                check(lib.merv_decode_attention_fused(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
-                                                      ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT,
-                                                      hd**-0.5, st), "merv_decode_attention_fused")
-                gemv(a.o_proj.weight, None, ptr(self.ao), x, x, D, H * hd)  # x += o_proj(attn)
+                if self.fuse_ao:  # rotary + cache + attention + merge + (x += o_proj(attn)): one launch
+                    check(lib.merv_decode_attn_oproj(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
+                                                     ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5,
+                                                     ptr(a.o_proj.weight), x, D, ptr(self.ao_counters) + 4 * li * self.ao_stride,
+                                                     ptr(self.chain_err), st), "merv_decode_attn_oproj")
+                else:
+                    check(lib.merv_decode_attention_fused(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
+                                                          ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT,
+                                                          hd**-0.5, st), "merv_decode_attention_fused")
+                    gemv(a.o_proj.weight, None, ptr(self.ao), x, x, D, H * hd)  # x += o_proj(attn)
                 gemv(mlp.gate_proj.weight, mlp.up_proj.weight, x, 0, ptr(self.mid), I, D, norm=lyr.post_attention_layernorm.weight)
                 gemv(mlp.down_proj.weight, None, ptr(self.mid), x, x, D, I)  # x += down_proj(...)
             gemv(m.lm_head.weight, None, x, 0, 0, self.cfg.vocab_size, D, y32=ptr(self.logits32), norm=m.model.norm.weight)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The one-launch decode step against the 5-launches-per-layer sequence: Llama-2-7B geometry (random init), a 1049-token prefill, then
+"""The one-launch decode step and the fused attention + o-projection launch against the 5-launches-per-layer sequence: Llama-2-7B geometry (random init), a 1049-token prefill, then
 N greedy steps through both; logits must be bit-identical; time per step of each (graph-replayed)."""
 import json
 import sys
@@ -21,8 +21,8 @@ def main():
     emb = torch.randn(1, 1049, cfg["hidden_size"], device=dev, dtype=torch.bfloat16) * 0.02
     out = {}
     logits = {}
-    for name, chain in (("launches", False), ("chain", True)):
-        HipDecoder.use_chain = chain
+    for name, chain, fuse in (("launches", False, False), ("attn_oproj", False, True), ("chain", True, False)):
+        HipDecoder.use_chain, HipDecoder.use_attn_oproj = chain, fuse
         d = HipDecoder(llm.llm, 1280, 1)
         tok = d.prefill(emb).argmax(-1)
         ls = []
@@ -38,12 +38,12 @@ def main():
             d.decode(tok)
         torch.cuda.synchronize()
         out[name + "_ms_per_step"] = round((time.perf_counter() - t0) / n * 1e3, 4)
-        if chain:
-            out["chain_err"] = int(d.chain_err.item())
+        out[name + "_err"] = int(d.chain_err.item())
         del d
-    out["bit_identical"] = bool(torch.equal(logits["launches"], logits["chain"]))
-    out["max_abs_diff"] = float((logits["launches"] - logits["chain"]).abs().max())
-    out["finite"] = bool(torch.isfinite(logits["chain"]).all())
+    for name in ("attn_oproj", "chain"):
+        out[name + "_bit_identical"] = bool(torch.equal(logits["launches"], logits[name]))
+        out[name + "_max_abs_diff"] = float((logits["launches"] - logits[name]).abs().max())
+    out["finite"] = bool(torch.isfinite(logits["chain"]).all() and torch.isfinite(logits["attn_oproj"]).all())
     print(json.dumps(out))
 
 
