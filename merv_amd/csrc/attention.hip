@@ -587,20 +587,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 constexpr int TV_ROW_TR = 192;  // row-major V image per wave: 32 rows x 192 B
 constexpr int TVT_ROW = 72;     // V^T image per wave: 64 d-rows x (32 keys * 2 B + 8 B pad)
 
-template <bool VTR>
-__global__ __launch_bounds__(256) void temporal_attn_kernel(TemporalAttnArgs p) {
+// NH: heads per block = consecutive waves that take the SAME four problems (32 rows): their loads are NH x 128 contiguous bytes per
+// row and tensor instead of 128 (DRAM pages, round 4: 111 against 122 us per layer at 16 videos with NH = 8).
+template <bool VTR, int NH>
+__global__ __launch_bounds__(NH > 4 ? NH * 64 : 256) void temporal_attn_kernel(TemporalAttnArgs p) {
+    constexpr int NWAVE = NH > 4 ? NH : 4;
     constexpr int WAVE_LDS = VTR ? 32 * TV_ROW_TR : 64 * TVT_ROW;
     constexpr int VROWB = VTR ? TV_ROW_TR : TVT_ROW;
-    __shared__ __attribute__((aligned(16))) char smem[4 * WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) char smem[NWAVE * WAVE_LDS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y;
+    const int head = blockIdx.y * NH + wave % NH;
     const int D = p.D, ld = 3 * D;
     const int NP = p.nclips * p.ntok;           // number of (clip, token) problems
-    const int pid0 = (blockIdx.x * 4 + wave) * 4;  // first of this wave's 4 problems
+    const int pid0 = (blockIdx.x * (NWAVE / NH) + wave / NH) * 4;  // first of this wave's 4 problems
     char* v_lds = smem + wave * WAVE_LDS;
 
     auto row_of = [&](int idx) -> size_t {  // idx in [0,32): problem idx>>3, frame idx&7
@@ -776,12 +779,21 @@ hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {
     if (a.nclips <= 0) return hipSuccess;
     if (a.t != 8 || a.D != a.heads * HD) return hipErrorInvalidValue;
     const int NP = a.nclips * a.ntok;
-    dim3 grid((NP + 15) / 16, a.heads);
     ProfScope ps(PROF_TATTN, s, 4.0 * NP * 64.0 * a.D, 2.0 * 4.0 * NP * 8.0 * a.D);
-    if (use_vtr())
-        hipLaunchKernelGGL(temporal_attn_kernel<true>, grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(temporal_attn_kernel<false>, grid, dim3(256), 0, s, a);
+    static const char* force = getenv("MERV_TATTN_NH");  // tuning hook: heads per block 1 / 4 / 8
+    int nh = a.heads % 8 == 0 ? 8 : (a.heads % 4 == 0 ? 4 : 1);  // 16 videos: 122 / 113.5 / 111 us per layer with 1 / 4 / 8 heads per block
+    if (force && (force[0] == '1' || (force[0] == '4' && a.heads % 4 == 0) || (force[0] == '8' && a.heads % 8 == 0))) nh = force[0] - '0';
+    auto go = [&](auto nh_tag) {
+        constexpr int NH = decltype(nh_tag)::value;
+        constexpr int NWAVE = NH > 4 ? NH : 4;
+        const int ppb = (NWAVE / NH) * 4;  // problems per block
+        dim3 grid((NP + ppb - 1) / ppb, a.heads / NH);
+        if (use_vtr()) hipLaunchKernelGGL((temporal_attn_kernel<true, NH>), grid, dim3(NWAVE * 64), 0, s, a);
+        else hipLaunchKernelGGL((temporal_attn_kernel<false, NH>), grid, dim3(NWAVE * 64), 0, s, a);
+    };
+    if (nh == 8) go(std::integral_constant<int, 8>{});
+    else if (nh == 4) go(std::integral_constant<int, 4>{});
+    else go(std::integral_constant<int, 1>{});
     return hipGetLastError();
 }
 

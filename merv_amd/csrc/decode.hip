@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(DecodeRopeArgs p) {
 // Each block takes positions [s * chunk, (s + 1) * chunk) of [0, pos]; every 16-lane group keeps a running (m, l, o[8]);
 // groups and waves are merged through LDS; the block writes (m, l, o[hd]) to the workspace.
 constexpr int DA_THREADS = 256;
-constexpr int DA_UN = 4;  // cache positions per 16-lane group per trip: 2 x DA_UN 16-byte loads in flight per lane
+constexpr int DA_UN = 4;  // cache positions per 16-lane group per trip: 2 x DA_UN 16-byte loads in flight per lane (8 / 12: 14.0 / 13.6 us against 14.0)
 
 struct DaState {  // running (max, sum, out[8 dims of this lane]) of one 16-lane group
     float m, l, o[8];
@@ -666,16 +666,29 @@ __global__ __launch_bounds__(512) void decode_attn_oproj_kernel(DecodeAttnOprojA
     unsigned* departed = p.counters + CHAIN_OP_STRIDE;   // workgroups that are past the wait and done
     if (wave >= 4) {  // loader waves: rows 4 (wave - 4) .. + 3 of the workgroup's 16
         const int r0 = 4 * (wave - 4);
-        for (int r = r0; r < r0 + 4; ++r) {
-            const bf16_t* src = p.Wo + (size_t)(bid * AO_ROWS + r) * K + lane * 8;
-            for (int pc = 0; pc < npc; ++pc)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 512),
-                                                 (__attribute__((address_space(3))) void*)(wbuf + ((size_t)r * K + pc * 512) * 2), 16, 0, 0);
-        }
-        // the attention body's three workgroup barriers (a fourth in the head's merging workgroup): raw, nothing to wait for yet
+        auto load_rows = [&](int ra, int rb) {
+            for (int r = ra; r < rb; ++r) {
+                const bf16_t* src = p.Wo + (size_t)(bid * AO_ROWS + r) * K + lane * 8;
+                for (int pc = 0; pc < npc; ++pc)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 512),
+                                                     (__attribute__((address_space(3))) void*)(wbuf + ((size_t)r * K + pc * 512) * 2), 16, 0, 0);
+            }
+        };
+        // the attention body's three workgroup barriers (a fourth in the head's merging workgroup): raw, nothing to wait for yet.
+        // MERV_AO_LOADER_LATE: the weight stream starts behind the first barrier (the attention's cache rows are through), half
+        // of it behind the second -- from the launch's start it competes with the attention's loads for the CU's memory path
+#ifdef MERV_AO_LOADER_LATE
+        __builtin_amdgcn_s_barrier();
+        load_rows(r0, r0 + 2);
+        __builtin_amdgcn_s_barrier();
+        load_rows(r0 + 2, r0 + 4);
+        __builtin_amdgcn_s_barrier();
+#else
+        load_rows(r0, r0 + 4);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");  // (the ticket was written before the third barrier: do not read it earlier)
         if (*(volatile unsigned*)&alds.ticket == (unsigned)(p.a.nsplit - 1)) __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have landed (before the barrier inside wait_input)

@@ -390,7 +390,8 @@ class HipDecoder(StaticDecoder):
     # The whole step as ONE launch (csrc/decode.hip, decode_chain_kernel): bit-identical but measured slower than the launches
     # (EXPERIMENTS.md section 5) -- opt-in, MERV_DECODE_CHAIN=1
     use_chain = os.environ.get("MERV_DECODE_CHAIN", "0") == "1"
-    use_attn_oproj = os.environ.get("MERV_DECODE_ATTN_OPROJ", "1") != "0"
+    # attention + o-projection as one launch: bit-identical, measured 2.4 us per layer SLOWER than the two launches -- opt-in too
+    use_attn_oproj = os.environ.get("MERV_DECODE_ATTN_OPROJ", "0") == "1"
 
     @staticmethod
     def chain_supported(hf_model) -> bool:
