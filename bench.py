@@ -180,11 +180,26 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
         torch.cuda.synchronize(); t0 = time.perf_counter(); m.encode(vv); torch.cuda.synchronize()
         t_enc = min(t_enc, time.perf_counter() - t0)
     dec = next(iter(llm._decoders.values()))
+    # the two LLM parts on their own: the prefill of the same length (PyTorch-ROCm) and the replayed decode step
+    n_pre = TOKENS_PER_VIDEO + len(prompt)
+    emb = torch.randn(1, n_pre, llm.config.hidden_size, device=device, dtype=torch.bfloat16) * 0.02
+    t_prefill = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); lg = dec.prefill(emb); torch.cuda.synchronize()
+        t_prefill = min(t_prefill, time.perf_counter() - t0)
+    tok = lg.argmax(-1)
+    for _ in range(3):
+        dec.decode(tok)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(32):
+        dec.decode(tok)
+    torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
     res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill on PyTorch-ROCm (SDPA), "
                    f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 5 launches per layer" if type(dec).__name__ == "HipDecoder"
                                                                 else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
            "new_tokens": int(out.shape[1]), "total_s": round(t, 4), "generated_tok_per_s": round(out.shape[1] / t, 2),
-           "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": TOKENS_PER_VIDEO + len(prompt)}
+           "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": n_pre,
+           "prefill_ms": round(t_prefill * 1e3, 2), "decode_ms_per_token": round(t_dec * 1e3, 3)}
     del m, llm
     torch.cuda.empty_cache()
     return res
@@ -369,7 +384,7 @@ def main():
             print(f"[bench] rank {rank}: {msg}; exiting with the headline only", file=sys.stderr, flush=True)
             if rank == 0:
                 print(json.dumps(make_line(dict(multi_gpu, error=msg), None, None, None, None)), file=real_stdout, flush=True)
-            os._exit(0)
+            os._exit(3)  # the launcher still gets the headline line, but a hung leg is recorded as a failure on every rank
 
         legs_timeout = float(os.environ.get("MERV_BENCH_LEGS_TIMEOUT", "300"))
         watchdog = threading.Timer(legs_timeout, legs_watchdog)
@@ -404,7 +419,8 @@ def main():
         except Exception as e:  # noqa: BLE001
             multi_gpu["error"] = f"{type(e).__name__}: {e}"
             print(f"[bench] rank {rank}: multi-GPU extra legs failed: {multi_gpu['error']}", file=sys.stderr, flush=True)
-        watchdog.cancel()
+        finally:
+            watchdog.cancel()
         flags = {k: v for k, v in multi_gpu.items() if k.endswith("_bit_equal_to_single_gpu_path")}
         print(f"[bench] rank {rank}/{world}: RCCL ranks {dist.get_world_size()}, placed legs bit-equal to the single-GPU path: {flags}, "
               f"error: {multi_gpu['error']}", file=sys.stderr, flush=True)

@@ -282,12 +282,15 @@ int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, in
  * 4: 256x128 with staggered half-blocks, 6: 128x128 four-deep ring, 7: 256x256 eight-phase where the shape allows it;
  * second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
+/* Tuning / test hook: the attention kernels' deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to
+ * 2^thr before its softmax reference moves); 0 = exact running maximum, default 8, values outside [0, 64] restore the default. */
+void merv_debug_set_attn_rescale_thr(float thr);
 /* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */
 int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t M, int32_t N, int32_t K, void *q_out,
                            void *scales_out, void *stream);
 /* test hook: the bf16 GEMM with the LayerNorm-partials output the encoder requests from the GEMMs that write its residual
  * stream: per row, per 64 output columns, {sum, M2 about the 64-column mean} of the bf16-rounded values stored
- * ([M][N/64][2] floats), which a one-thread-per-row kernel combines (Chan) into the statistics of a LayerNorm folded into
+ * ([N/64][M][2] floats: column tile major), which a one-thread-per-row kernel combines (Chan) into the statistics of a LayerNorm folded into
  * the next GEMM. */
 int merv_debug_gemm_stats(const void *A, const void *W, void *C, const float *bias, const float *lscale, const void *res,
                           int32_t M, int32_t N, int32_t K, int32_t act, float *stats_out, void *stream);

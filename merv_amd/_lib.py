@@ -120,6 +120,7 @@ SIGNATURES = {
     "merv_decode_chain_counter_bytes": (_sz, [_i32]),
     "merv_decode_chain_step": (C.c_int, [_vp, _vp]),
     "merv_debug_set_gemm_variant": (None, [_i32]),
+    "merv_debug_set_attn_rescale_thr": (None, [_f32]),
     "merv_prof_enable": (None, [_i32]),
     "merv_prof_reset": (None, []),
     "merv_prof_read": (C.c_int, [_i32, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_f64)]),

@@ -13,6 +13,7 @@
 // exponentiated tile is already in B-operand order for O^T = V^T P^T: no LDS round trip for P.
 // V^T fragments come either from a row-major V tile read with the hardware transpose load
 // (ds_read_b64_tr_b16, VTR = true) or from a tile transposed while staging (VTR = false).
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -726,6 +727,14 @@ __global__ __launch_bounds__(NH > 4 ? NH * 64 : 256) void temporal_attn_kernel(T
 
 }  // namespace
 
+static float initial_rescale_thr() {
+    const char* e = getenv("MERV_ATTN_RESCALE_THR");
+    const float v = e ? (float)atof(e) : 8.0f;
+    return (v >= 0.f && v <= 64.f) ? v : 8.0f;
+}
+static std::atomic<float> g_attn_rescale_thr{initial_rescale_thr()};
+void set_attn_rescale_thr(float thr) { g_attn_rescale_thr.store((thr >= 0.f && thr <= 64.f) ? thr : 8.0f, std::memory_order_relaxed); }
+
 // MERV_ATTN_VTR=0 in the environment selects the transposing-store V path (diagnostic switch, re-read per launch).
 static bool use_vtr() {
     const char* e = getenv("MERV_ATTN_VTR");
@@ -748,11 +757,9 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (a_in.nseq <= 0 || a_in.L <= 0) return hipSuccess;
     if (a_in.D != a_in.heads * HD) return hipErrorInvalidValue;
     AttnArgs a = a_in;
-    {   // deferred-max threshold in binary orders of magnitude; MERV_ATTN_RESCALE_THR=0 gives the exact running maximum (test hook)
-        const char* e = getenv("MERV_ATTN_RESCALE_THR");
-        a.rescale_thr = e ? (float)atof(e) : 8.0f;
-        if (!(a.rescale_thr >= 0.f) || a.rescale_thr > 64.f) a.rescale_thr = 8.0f;
-    }
+    // deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to 2^thr before its reference moves);
+    // merv_debug_set_attn_rescale_thr (tests, probes) overrides the default, MERV_ATTN_RESCALE_THR sets it once per process
+    a.rescale_thr = g_attn_rescale_thr.load(std::memory_order_relaxed);
     ProfScope ps(PROF_ATTN, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
     // block shape. Short sequences: least padded query tiles -- 257- / 261-token sequences are exactly 9 tiles = 3 waves
     // x 3, streamed once per (sequence, head). Long sequences (ViViT, 3137 tokens = 99 tiles): 4 waves x 2 even at 5 %

@@ -706,6 +706,7 @@ extern "C" int merv_preprocess_languagebind(const void* frames_u8, int32_t T, in
 
 // Tuning / test hook: force a GEMM tile configuration (0 = automatic choice).
 extern "C" void merv_debug_set_gemm_variant(int32_t v) { set_gemm_variant(v); }
+extern "C" void merv_debug_set_attn_rescale_thr(float thr) { set_attn_rescale_thr(thr); }
 
 // ---- single-kernel wrappers ----
 extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* lscale,

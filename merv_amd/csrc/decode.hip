@@ -858,7 +858,11 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     static const char* cfg = getenv("MERV_GEMV_CFG");  // tuning hook: "<rows><un>", e.g. "14", "18", "24"
     const long rows_total = (long)a.N + a.Nb + a.Nc;
     int rows = (!a.W2 && !a.norm_w && rows_total <= 16384) ? 1 : 2, un = rows == 1 ? 8 : 4;
-    if (cfg && cfg[0] && cfg[1]) { rows = cfg[0] - '0'; un = cfg[1] - '0'; }
+    // only the three instantiated configurations; one row per wave never with a fused norm (every wave would repeat the reduction)
+    if (cfg && cfg[0] && cfg[1] && !cfg[2]) {
+        const int r = cfg[0] - '0', u = cfg[1] - '0';
+        if ((r == 2 && u == 4) || (r == 1 && (u == 4 || u == 8) && !a.norm_w)) { rows = r; un = u; }
+    }
     if (rows == 1 && un == 8) return launch_gemv_cfg<1, 8>(a, s);
     if (rows == 1) return launch_gemv_cfg<1, 4>(a, s);
     return launch_gemv_cfg<2, 4>(a, s);

@@ -1185,8 +1185,9 @@ int choose_variant(const GemmArgs& a) {
     if (small_tiles <= num_cus()) return 6;
     // 128-159 tiles of 256 x 128 (what ViViT / SigLIP leave of their N = 768 GEMMs at 16 videos: 6672 rows = 156 tiles): more
     // 128 x 128 blocks than CUs, and the staggered 256 x 128 kernel on half a round beats two co-resident 128 x 128 blocks
-    // per CU by 2 x (14.1 vs 27.3 us at K = 768, 35.7 vs 86.1 at K = 3072; tools/probes/gemm_remainder.py)
-    return 4;
+    // per CU by 2 x (14.1 vs 27.3 us at K = 768, 35.7 vs 86.1 at K = 3072; tools/probes/gemm_remainder.py). Measured at M = 3328 and
+    // 6656 only: a few rows under a very wide N (M <= 1024: up to half of a 256-row tile would be padding) keep the 128 x 128 tile.
+    return a.M > 1024 ? 4 : 1;
 }
 
 constexpr long SUBROUND_MIN_TILES = 32;

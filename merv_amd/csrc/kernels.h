@@ -137,6 +137,7 @@ struct AttnArgs {
     int q_prescaled;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+void set_attn_rescale_thr(float thr);  // test / probe hook (default 8, or MERV_ATTN_RESCALE_THR read once per process)
 
 // LanguageBind temporal attention: for every (clip, token, head) an 8x8 attention over the clip's t frames.
 // Rows are frame-major: row = frame * ntok + token, frame = clip * t + i (modeling_video.py:133-155).

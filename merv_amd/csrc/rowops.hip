@@ -419,7 +419,8 @@ hipError_t launch_layernorm(const LayerNormArgs& a, hipStream_t s) {
     if (a.M <= 0) return hipSuccess;
     if (a.D % 8 != 0 || a.D > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
     if (a.add && (a.add_div <= 0 || a.add_mod <= 0)) return hipErrorInvalidValue;
-    ProfScope ps(PROF_LN, s, 0.0, 4.0 * a.M * (double)a.D);
+    // algorithmic bytes: x read + y written; with the fused temporal-embedding add, x is also written back (2 M D more)
+    ProfScope ps(PROF_LN, s, 0.0, (a.add ? 6.0 : 4.0) * a.M * (double)a.D);
     hipLaunchKernelGGL(layernorm_kernel, dim3((a.M + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -122,3 +122,66 @@ def test_quick_start_script_shape(tmp_path, dev):
     generated_text = vidlm.generate(str(video_path), prompt_text, num_frames=[4], do_sample=True, temperature=0.4,
                                     max_new_tokens=5, min_length=1)
     assert isinstance(generated_text, str) and 1 <= len(generated_text.split()) <= 5
+
+
+def test_eval_mcq_script_shape(tmp_path, dev, monkeypatch):
+    """The call sequence of the reference's scripts/eval_mcq.py:100-160, in its order, through the `merv` alias:
+    `from merv.models.load_vid import load_vid`, `load_vid(run, hf_token=..., get_model_cfg=True)`, `.to(device, bf16)`, per question
+    `vidlm.llm_backbone.prompt_builder_fn(model_family="merv")`, `add_turn`, `get_prompt`, then `generate(video_name, prompt_text,
+    do_sample=..., temperature=..., max_new_tokens=..., min_length=..., num_frames=model_cfg.num_frames, clip_start_sec=...,
+    clip_end_sec=..., end_frame=...)` with the dummy_mcq question's `end_frame = 595`. The clip is pre-decoded (decord is absent): a
+    (frames, fps) pair of 900 frames stands for the file, and the frames the library selects are checked against the reference's
+    expression (datasets.py:131-141: np.linspace(start, min(end, end_frame), n, dtype=int)) and against what reaches the encoder."""
+    import numpy as np
+    from merv.models.load_vid import load_vid  # the alias package at the repo root, as the script imports it
+    import merv_amd.video_io as vio
+
+    class Tok:
+        def __call__(self, text):
+            self.last_text = text
+            return [1] + [3 + (ord(c) % 200) for c in text][:24]
+
+        def decode(self, ids):
+            return " ".join(str(i) for i in ids)
+
+    run, *_ = _write_run(tmp_path, dev)
+    tok = Tok()
+    vidlm, model_cfg = load_vid(str(run), hf_token="unused", get_model_cfg=True, llm_config=TINY_LLM, tokenizer=tok, device=dev)
+    vidlm.to(dev, dtype=torch.bfloat16)
+    num_frames = model_cfg["num_frames"] if isinstance(model_cfg, dict) else model_cfg.num_frames
+    assert list(num_frames) == [4]
+
+    # frame i is filled with the value i % 251 (and i // 251 in the blue channel), so a selected frame names its index
+    n_frames, fps = 900, 29.97
+    idx = torch.arange(n_frames)
+    clip = torch.zeros(n_frames, 24, 32, 3, dtype=torch.uint8)
+    clip[..., 0] = (idx % 251)[:, None, None].to(torch.uint8)
+    clip[..., 1] = (idx % 251)[:, None, None].to(torch.uint8)
+    clip[..., 2] = (idx // 251)[:, None, None].to(torch.uint8)
+    seen = {}
+    orig = vio.load_video
+
+    def spy(video, **kw):
+        out = orig(video, **kw)
+        seen["kw"] = kw
+        seen["ids"] = (out[:, 0, 0, 0].long() + 251 * out[:, 2, 0, 0].long()).tolist()
+        return out
+
+    monkeypatch.setattr(vio, "load_video", spy)
+    question = {"question_id": 0, "video_name": "dummy", "end_frame": 595, "question": "What is shown?", "a0": "a cat", "a1": "a dog"}
+    prompt_builder = vidlm.llm_backbone.prompt_builder_fn(model_family="merv")
+    question_text = question["question"] + " Options: (A) a cat (B) a dog. Answer with the option's letter."
+    prompt_builder.add_turn(role="human", message=question_text)
+    prompt_text = prompt_builder.get_prompt()
+    assert prompt_text == f"In: {question_text}\nOut:"
+    clip_start_sec = question["time"][0] if "time" in question else 0.0
+    clip_end_sec = question["time"][1] if "time" in question else None
+    end_frame = question["end_frame"] if "end_frame" in question else None
+    generated_text = vidlm.generate((clip, fps), prompt_text, do_sample=False, temperature=0.0, max_new_tokens=4, min_length=1,
+                                    num_frames=num_frames, clip_start_sec=clip_start_sec, clip_end_sec=clip_end_sec, end_frame=end_frame)
+    assert isinstance(generated_text, str) and 1 <= len(generated_text.split()) <= 4
+    assert tok.last_text == prompt_text
+    # datasets.py:131-141 with clip_start_sec = 0, clip_end_sec = None, end_frame = 595: linspace(0, min(N - 1, 595), 4) as ints
+    expect = np.linspace(0, min(n_frames - 1, 595), max(num_frames), dtype=int).tolist()
+    assert seen["kw"]["end_frame"] == 595 and seen["kw"]["num_frames"] == max(num_frames)
+    assert seen["ids"] == expect == [0, 198, 396, 595]

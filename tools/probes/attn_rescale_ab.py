@@ -9,7 +9,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 import torch
 
-from merv_amd import ops
+from merv_amd import _lib, ops
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -21,7 +21,7 @@ for name, nseq, L, heads in [("languagebind", 16 * B, 257, 16), ("dinov2", 16 * 
     times, outs = {t: [] for t in thrs}, {}
     for rnd in range(4):
         for t in thrs:
-            os.environ["MERV_ATTN_RESCALE_THR"] = t
+            _lib.load().merv_debug_set_attn_rescale_thr(float(t))
             o = ops.attention(qkv, nseq, L, heads)
             if rnd == 0:
                 outs[t] = o.float().clone()
@@ -32,6 +32,6 @@ for name, nseq, L, heads in [("languagebind", 16 * B, 257, 16), ("dinov2", 16 * 
             e1.record()
             torch.cuda.synchronize()
             times[t].append(e0.elapsed_time(e1) / 10)
-    os.environ.pop("MERV_ATTN_RESCALE_THR", None)
+    _lib.load().merv_debug_set_attn_rescale_thr(8.0)
     base = outs[thrs[0]]
     print(f"attn {name:13s} L={L:5d}: " + " | ".join(f"thr {t}: {min(v)*1e3:7.1f} us  d={float((outs[t]-base).norm()/base.norm()):.1e}" for t, v in times.items()), flush=True)
