@@ -41,7 +41,7 @@ BACKBONE_IDS = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-
                 "siglip-vit-b16-224px-all-no-cls"]  # merv/conf/models.py:106-113
 NUM_FRAMES = [16, 16, 32, 16]  # merv/conf/models.py:118
 TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance
-PMC_TRAFFIC_FILE = "profiles/r03_pmc_gemm_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r04_pmc_gemm_traffic.json"
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters; 6.29 TB/s is the measured copy rate)
 # kernel-level profiler classes of libmerv_hip.so (include/merv_hip.h, merv_prof_*): (class, name, bound, kernels)
 KERNEL_CLASSES = [
@@ -184,16 +184,17 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
     n_pre = TOKENS_PER_VIDEO + len(prompt)
     emb = torch.randn(1, n_pre, llm.config.hidden_size, device=device, dtype=torch.bfloat16) * 0.02
     t_prefill = 1e9
-    for _ in range(3):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); lg = dec.prefill(emb); torch.cuda.synchronize()
-        t_prefill = min(t_prefill, time.perf_counter() - t0)
-    tok = lg.argmax(-1)
-    for _ in range(3):
-        dec.decode(tok)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(32):
-        dec.decode(tok)
-    torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
+    with torch.inference_mode():  # (the decoder's buffers were created inside generate()'s inference mode)
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); lg = dec.prefill(emb); torch.cuda.synchronize()
+            t_prefill = min(t_prefill, time.perf_counter() - t0)
+        tok = lg.argmax(-1)
+        for _ in range(3):
+            dec.decode(tok)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(32):
+            dec.decode(tok)
+        torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
     res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill on PyTorch-ROCm (SDPA), "
                    f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 5 launches per layer" if type(dec).__name__ == "HipDecoder"
                                                                 else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
@@ -497,7 +498,7 @@ def main():
         if roof is not None:
             roof["by_kernel"] = by_kernel
             roof["by_kernel_note"] = (f"one HIP-event bracket per kernel launch, encoders on ONE stream, {args.steps} steps; the classes partition the "
-                                      f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r03_kernel_roofline.json "
+                                      f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r04_kernel_roofline.json "
                                       "joins the same classes to a rocprofv3 --kernel-trace of the same command")
 
     parity = cpu = e2e = None

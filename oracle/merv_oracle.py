@@ -411,8 +411,9 @@ def splice(input_embeddings: torch.Tensor, fused: torch.Tensor, bos_token_length
 
 
 # ------------------------------------------------------------------------------------------------------------
-# f-4. training-mode batch assembly and loss -- merv/models/vidlms/merv.py:612-734 (unpinned: MERV.forward cannot be
-# imported here; restated line by line). Gradients of the projector / fusion parameters are torch autograd through
+# f-4. training-mode batch assembly and loss -- merv/models/vidlms/merv.py:612-734, restated line by line and pinned (since
+# round 3) on the reference's own MERV.forward body run from its AST (tools/make_goldens.py, tests/golden/merv_forward.npz,
+# tests/test_oracle_goldens.py). Gradients of the projector / fusion parameters are torch autograd through
 # projector_forward / fusion_forward above, exactly what the reference's loss.backward() differentiates.
 # ------------------------------------------------------------------------------------------------------------
 def assemble_training_batch(input_embeddings: torch.Tensor, fused: torch.Tensor, attention_mask: torch.Tensor,

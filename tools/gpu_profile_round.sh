@@ -17,6 +17,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 cat $OUT/trace_bench.json
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 python3 $R/tools/kernel_roofline.py $OUT/bench.json $OUT/kernel_stats.csv 8 $OUT/kernel_roofline.json
+bash $R/tools/pmc_gemm_round.sh > $OUT/pmc_gemm.log 2>&1; cp $R/gpurun_out/pmc_round/pmc_gemm.json $OUT/pmc_gemm.json
+bash $R/tools/pmc_attn.sh > $OUT/pmc_attn.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --sequential --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-prof > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --sequential --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-prof > /dev/null 2> $OUT/pmc_write.err
 python3 - $OUT <<'PY'
