@@ -830,6 +830,28 @@ extern "C" int merv_decode_rope_cache(const void* q, const void* k, const void* 
     return 0;
 }
 
+extern "C" int merv_prefill_rope_cache(void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos_t,
+                                       const void* sin_t, int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
+                                       void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && k_cache && v_cache && cos_t && sin_t, "merv_prefill_rope_cache: null argument");
+    MERV_CHECK(S > 0 && pos0 >= 0 && H > 0 && Hkv > 0 && hd > 0 && hd % 16 == 0 && max_len > 0 && pos0 + S <= max_len,
+               "merv_prefill_rope_cache: bad geometry (hd % 16 == 0, pos0 + S <= max_len required)");
+    PrefillRopeArgs a{(bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)k_cache, (bf16_t*)v_cache, (const bf16_t*)cos_t,
+                      (const bf16_t*)sin_t, S, pos0, H, Hkv, hd, max_len};
+    MERV_HIP(launch_prefill_rope_cache(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_silu_mul(const void* gate, const void* up, void* out, int64_t n, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(gate && up && out, "merv_silu_mul: null argument");
+    MERV_CHECK(n > 0 && n % 8 == 0, "merv_silu_mul: n > 0 and n % 8 == 0 required");
+    SiluMulArgs a{(const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)out, (long)n};
+    MERV_HIP(launch_silu_mul(a, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" size_t merv_decode_attention_workspace_floats(int32_t H, int32_t nsplit) {
     if (H <= 0 || nsplit <= 0) return 0;
     return (size_t)H * nsplit * (128 + 2);

@@ -359,6 +359,64 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(DecodeRopeArgs p) {
     }
 }
 
+// ---- prompt prefill: rotary embedding of S positions + cache fill, 16 bytes per lane ----
+// One item = 8 elements d0 .. d0 + 7 of the first half of a (position, head) vector together with its partners d0 + hd / 2 ..
+// (rotate_half pairs them), so q can be rotated in place; the v items are plain 16-byte copies into the cache.
+__global__ __launch_bounds__(256) void prefill_rope_cache_kernel(PrefillRopeArgs p) {
+    const int hc = p.hd >> 4;                       // 8-element chunks per half vector
+    const int per_row = (p.H + p.Hkv) * hc + p.Hkv * 2 * hc;
+    const long total = (long)p.S * per_row;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int s = (int)(g / per_row);
+        int it = (int)(g - (long)s * per_row);
+        const long pos = p.pos0 + s;
+        if (it < (p.H + p.Hkv) * hc) {
+            const int head = it / hc, d0 = (it - head * hc) * 8, half = p.hd >> 1;
+            const bool is_q = head < p.H;
+            const bf16_t* src = is_q ? p.q + ((size_t)s * p.H + head) * p.hd : p.k + ((size_t)s * p.Hkv + (head - p.H)) * p.hd;
+            float lo[8], hi[8], cl[8], ch[8], sl[8], sh[8];
+            unpack8f(*(const u32x4*)(src + d0), lo);
+            unpack8f(*(const u32x4*)(src + d0 + half), hi);
+            unpack8f(*(const u32x4*)(p.cos + pos * p.hd + d0), cl);
+            unpack8f(*(const u32x4*)(p.cos + pos * p.hd + d0 + half), ch);
+            unpack8f(*(const u32x4*)(p.sin + pos * p.hd + d0), sl);
+            unpack8f(*(const u32x4*)(p.sin + pos * p.hd + d0 + half), sh);
+            u32x4 olo, ohi;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // x * cos + rotate_half(x) * sin, every product and the sum rounded to bf16 (rope_cache_kernel)
+                const int a = 2 * j, b = 2 * j + 1;
+                olo[j] = pack2bf(round_bf(lo[a] * cl[a]) + round_bf(-hi[a] * sl[a]), round_bf(lo[b] * cl[b]) + round_bf(-hi[b] * sl[b]));
+                ohi[j] = pack2bf(round_bf(hi[a] * ch[a]) + round_bf(lo[a] * sh[a]), round_bf(hi[b] * ch[b]) + round_bf(lo[b] * sh[b]));
+            }
+            bf16_t* dst = is_q ? p.q + ((size_t)s * p.H + head) * p.hd : p.k_cache + ((size_t)(head - p.H) * p.max_len + pos) * p.hd;
+            *(u32x4*)(dst + d0) = olo;
+            *(u32x4*)(dst + d0 + half) = ohi;
+        } else {
+            it -= (p.H + p.Hkv) * hc;
+            const int hv = it / (2 * hc), d0 = (it - hv * 2 * hc) * 8;
+            *(u32x4*)(p.v_cache + ((size_t)hv * p.max_len + pos) * p.hd + d0) = *(const u32x4*)(p.v + ((size_t)s * p.Hkv + hv) * p.hd + d0);
+        }
+    }
+}
+
+// ---- prompt prefill: silu(gate) * up on materialised tensors (the decode step has it inside its GEMV pair) ----
+__global__ __launch_bounds__(256) void silu_mul_kernel(SiluMulArgs p) {
+    const long nchunk = p.n >> 3;
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nchunk; c += (long)gridDim.x * 256) {
+        float g[8], u[8];
+        unpack8f(*(const u32x4*)(p.gate + c * 8), g);
+        unpack8f(*(const u32x4*)(p.up + c * 8), u);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float s0 = round_bf(g[2 * j] / (1.f + __expf(-g[2 * j])));  // F.silu on a bf16 tensor
+            const float s1 = round_bf(g[2 * j + 1] / (1.f + __expf(-g[2 * j + 1])));
+            o[j] = pack2bf(s0 * u[2 * j], s1 * u[2 * j + 1]);
+        }
+        *(u32x4*)(p.out + c * 8) = o;
+    }
+}
+
 // ---- decode attention: grid (H, nsplit); 16 lanes per cache position (16 B of a 128-wide K / V row each; hd == 128) ----
 // Each block takes positions [s * chunk, (s + 1) * chunk) of [0, pos]; every 16-lane group keeps a running (m, l, o[8]);
 // groups and waves are merged through LDS; the block writes (m, l, o[hd]) to the workspace.
@@ -872,6 +930,22 @@ hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s) {
     if (a.hd % 2 != 0 || a.H <= 0 || a.Hkv <= 0) return hipErrorInvalidValue;
     const int total = (a.H + 2 * a.Hkv) * a.hd;
     hipLaunchKernelGGL(rope_cache_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_prefill_rope_cache(const PrefillRopeArgs& a, hipStream_t s) {
+    if (a.S <= 0) return hipSuccess;
+    if (a.hd % 16 != 0 || a.H <= 0 || a.Hkv <= 0 || a.pos0 < 0 || a.pos0 + a.S > a.max_len) return hipErrorInvalidValue;
+    const long total = (long)a.S * ((a.H + a.Hkv) * (a.hd / 16) + a.Hkv * (a.hd / 8));
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(prefill_rope_cache_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_silu_mul(const SiluMulArgs& a, hipStream_t s) {
+    if (a.n <= 0) return hipSuccess;
+    if (a.n % 8 != 0) return hipErrorInvalidValue;
+    const long blocks = ((a.n >> 3) + 255) / 256;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -244,6 +244,7 @@ def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
                     pr.bias.normal_(0, 0.5)
     assert HipDecoder.supports(llm.llm, 1) and not HipDecoder.supports(llm.llm, 2)
     ref, hip, hip_eager = StaticDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1)
+    hip.use_hip_prefill = hip_eager.use_hip_prefill = False  # the decode steps alone: all three start from the same PyTorch prefill
     emb = (torch.randn(1, 37, 256, generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16).to(dev)
     l_ref, l_hip = ref.prefill(emb), hip.prefill(emb)
     hip_eager.prefill(emb)
@@ -262,6 +263,91 @@ def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
         if float(top2[0] - top2[1]) > 0.05 * float(l_ref[0].abs().max()):  # a clear winner: both decoders pick it
             assert int(l_hip.argmax(-1)) == int(l_ref.argmax(-1))
     print(f"HipDecoder vs StaticDecoder ({family}, kv heads {kv_heads}): worst logits rel-L2 {worst:.3e}")
+
+
+def test_prefill_rope_cache_rows(dev):
+    """merv_prefill_rope_cache == the module's expression q * cos + rotate_half(q) * sin on bf16 tensors, bit for bit, q in place,
+    k / v into the cache rows pos0 .. pos0 + S - 1 (other rows untouched)."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    S, H, Hkv, hd, max_len, pos0 = 37, 4, 2, 128, 64, 5
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    q, k, v = bf(torch.randn(S, H * hd, generator=g)), bf(torch.randn(S, Hkv * hd, generator=g)), bf(torch.randn(S, Hkv * hd, generator=g))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    emb = torch.outer(torch.arange(max_len, dtype=torch.float32), inv)
+    emb = torch.cat([emb, emb], -1)
+    cos, sin = bf(emb.cos()), bf(emb.sin())
+    rot = lambda x: torch.cat([-x[..., hd // 2:], x[..., :hd // 2]], -1)
+    c, s_ = cos[pos0:pos0 + S][:, None], sin[pos0:pos0 + S][:, None]
+    q4, k4 = q.view(S, H, hd), k.view(S, Hkv, hd)
+    q_ref = q4 * c + rot(q4) * s_
+    k_ref = k4 * c + rot(k4) * s_
+    Kc = bf(torch.randn(Hkv, max_len, hd, generator=g))
+    Vc = bf(torch.randn(Hkv, max_len, hd, generator=g))
+    K0, V0 = Kc.clone(), Vc.clone()
+    check(lib.merv_prefill_rope_cache(ptr(q), ptr(k), ptr(v), ptr(Kc), ptr(Vc), ptr(cos), ptr(sin), S, pos0, H, Hkv, hd, max_len, _st(dev)), "rope")
+    assert torch.equal(q.view(S, H, hd), q_ref)
+    assert torch.equal(Kc[:, pos0:pos0 + S], k_ref.transpose(0, 1)) and torch.equal(Vc[:, pos0:pos0 + S], v.view(S, Hkv, hd).transpose(0, 1))
+    keep = torch.ones(max_len, dtype=torch.bool)
+    keep[pos0:pos0 + S] = False
+    assert torch.equal(Kc[:, keep], K0[:, keep]) and torch.equal(Vc[:, keep], V0[:, keep])
+
+
+def test_silu_mul(dev):
+    """merv_silu_mul == F.silu(gate) * up on bf16 tensors (in place into gate as well)."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(12)
+    gate = (torch.randn(333, 1376, generator=g) * 3).to(torch.bfloat16).to(dev)
+    up = torch.randn(333, 1376, generator=g).to(torch.bfloat16).to(dev)
+    ref = F.silu(gate) * up
+    out = torch.empty_like(gate)
+    check(lib.merv_silu_mul(ptr(gate), ptr(up), ptr(out), gate.numel(), _st(dev)), "silu_mul")
+    diff = (out.float() - ref.float()).abs()
+    ulp = ref.float().abs() * 2.0 ** -7 + 1e-30
+    assert float((diff / ulp).max()) <= 1.0 and float((diff > 0).float().mean()) < 1e-3  # exp() implementations differ in the last place, rarely
+    check(lib.merv_silu_mul(ptr(gate), ptr(up), ptr(gate), gate.numel(), _st(dev)), "silu_mul in place")
+    assert torch.equal(gate, out)
+
+
+@pytest.mark.parametrize("kv_heads,family", [(2, "llama"), (1, "llama3.1"), (1, "qwen2")])
+def test_hip_prefill_matches_pytorch_prefill(dev, kv_heads, family):
+    """HipDecoder's prefill (RMSNorm / rotary + cache fill / silu * up on the library's kernels, GEMMs and attention on PyTorch-ROCm)
+    against StaticDecoder's plain PyTorch expression: same rounding points, so caches and logits agree to bf16 rounding noise."""
+    from merv_amd.llm import HipDecoder, LlamaBackbone, StaticDecoder
+    cfg = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+               num_key_value_heads=kv_heads, max_position_embeddings=2048, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    if family == "llama3.1":
+        cfg.update(rope_theta=500000.0, rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                                      "high_freq_factor": 4.0, "original_max_position_embeddings": 64})
+        family = "llama"
+    if family == "qwen2":
+        cfg.update(rope_theta=1e6, tie_word_embeddings=True, use_sliding_window=False)
+    llm = LlamaBackbone(cfg, device=dev, family=family)
+    if family == "qwen2":
+        with torch.no_grad():
+            for lyr in llm.llm.model.layers:
+                for pr in (lyr.self_attn.q_proj, lyr.self_attn.k_proj, lyr.self_attn.v_proj):
+                    pr.bias.normal_(0, 0.5)
+    ref, hip = StaticDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1)
+    assert hip.use_hip_prefill
+    emb = (torch.randn(1, 77, 256, generator=torch.Generator().manual_seed(4)) * 0.5).to(torch.bfloat16).to(dev)
+    emb0 = emb.clone()
+    l_ref, l_hip = ref.prefill(emb), hip.prefill(emb)
+    assert torch.equal(emb, emb0)  # the caller's embeddings are not the in-place residual stream
+    assert int(hip.pos) == 77 == int(ref.pos)
+    assert rel_l2(l_hip, l_ref) < 2e-2
+    for li in range(3):
+        assert rel_l2(hip.K[li][:, :, :77], ref.K[li][:, :, :77]) < 2e-2 and rel_l2(hip.V[li][:, :, :77], ref.V[li][:, :, :77]) < 2e-2
+        assert float(hip.K[li][:, :, 77:].abs().max()) == 0.0
+    assert torch.equal(hip.K[0][:, :, :77], ref.K[0][:, :, :77])  # layer 0: same inputs, same rounding points (RMSNorm sums aside)
+    # decoding continues from either prefill
+    tok = l_ref.argmax(-1)
+    a, b = ref.decode(tok, use_graph=False), hip.decode(tok, use_graph=False)
+    assert rel_l2(b, a) < 2e-2
 
 
 def test_generate_uses_hip_decoder_when_it_can(dev):
