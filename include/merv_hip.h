@@ -339,10 +339,17 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
  * LlamaDecoderLayer.forward): merv_decode_rmsnorm takes rows = S; these two do the rest.
  *  merv_prefill_rope_cache  apply_rotary_pos_emb on positions pos0 .. pos0 + S - 1: q [S, H*hd] rotated IN PLACE, rot(k [S, Hkv*hd]) ->
  *                           k_cache[:, pos0 + s], v -> v_cache[:, pos0 + s]; caches [Hkv, max_len, hd], tables [max_len, hd]; hd % 16 == 0
- *  merv_silu_mul            out = bf16(bf16(silu(gate)) * up), n elements (n % 8 == 0); out may alias gate or up */
+ *  merv_silu_mul            out = bf16(bf16(silu(gate)) * up), n elements (n % 8 == 0); out may alias gate or up
+ *  merv_prefill_attention   causal softmax(q k^T * scale) v of ONE sequence of S positions, hd = 128, GQA (kv head = h / (H / Hkv)):
+ *                           replaces F.scaled_dot_product_attention(q, k, v, is_causal=True) of LlamaAttention.forward on the prompt.
+ *                           q [S, ldq] (head h at columns 128 h ..; rotary applied), k / v: kv head g, position s at
+ *                           base + g * kv_head_stride + s * ldk (the KV cache itself: ldk = 128, kv_head_stride = max_len * 128),
+ *                           out [S, ldo] in q's column layout -- the o-projection's input, no transpose */
 int merv_prefill_rope_cache(void *q, const void *k, const void *v, void *k_cache, void *v_cache, const void *cos_t, const void *sin_t,
                             int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, void *stream);
 int merv_silu_mul(const void *gate, const void *up, void *out, int64_t n, void *stream);
+int merv_prefill_attention(const void *q, const void *k, const void *v, void *out, int32_t S, int32_t H, int32_t Hkv, int32_t hd,
+                           int32_t ldq, int32_t ldk, int64_t kv_head_stride, int32_t ldo, float scale, void *stream);
 /* three projections of the same input in one launch (q_proj / k_proj / v_proj): y_i[N_i] = bf16(W_i[N_i,K] x[K]) */
 int merv_decode_gemv3(const void *Wa, const void *Wb, const void *Wc, const void *x, void *ya, void *yb, void *yc,
                       int32_t Na, int32_t Nb, int32_t Nc, int32_t K, const void *norm_w, float norm_eps, void *stream);

@@ -581,6 +581,210 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Causal self attention of the LLM prompt prefill (row f-3): head_dim = 128, one sequence, GQA. The same transposed-score scheme
+// as attn_kernel -- S^T = K Q^T per 64-key tile (8 k-steps), one query per lane, P already in B-operand order for O^T = V^T P^T
+// (4 d-blocks), deferred running maximum with the chain seeded by -m -- re-parameterised: K / V rows are 256 B (the KV cache's
+// rows), a block is 4 waves x 32 queries of one head, and the key-tile loop of a block stops at its last query's tile; inside the
+// diagonal tiles keys past the lane's query are masked. Blocks are dispatched longest-first (the last query block has the most
+// key tiles). Replaces F.scaled_dot_product_attention(..., is_causal=True) inside LlamaAttention.forward for the prompt
+// (merv/models/vidlms/merv.py:723-734 -> LlamaForCausalLM.forward): 145 us per layer there at 1049 tokens x 32 heads.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PA_HD = 128, PA_KROW = 256, PA_VROW = 320;  // V rows padded to 320 B: four rows' 64-byte column groups tile the 256-B bank row
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(PrefillAttnArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int STG = 1024 / NT;  // 16-byte chunks of a 64 x 128 bf16 tile per thread
+    constexpr int K_BYTES = 64 * PA_KROW, V_BYTES = 64 * PA_VROW, OUT_BYTES = NW * 32 * 256;
+    constexpr int LDS_BYTES = (K_BYTES + V_BYTES) > OUT_BYTES ? (K_BYTES + V_BYTES) : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    char* k_lds = smem;
+    char* v_lds = smem + K_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int head = blockIdx.y, kvh = head / (p.H / p.Hkv);
+    const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;  // longest blocks first
+    const int S = p.S;
+    const int q0 = qb * (NW * 32), qw = q0 + wave * 32;  // first query of the block / of this wave
+    const bf16_t* kbase = p.k + (size_t)kvh * p.kv_head_stride;
+    const bf16_t* vbase = p.v + (size_t)kvh * p.kv_head_stride;
+
+    // Q^T B-operand fragments: element j of step s = Q[q][16 s + 8 h + j], scaled to log2 units (scale * log2 e, re-rounded to bf16)
+    const float sc = p.scale * LOG2E;
+    bf16x8 qf[8];
+    {
+        const int q_row = qw + r < S ? qw + r : S - 1;
+        const bf16_t* qp = p.q + (size_t)q_row * p.ldq + head * PA_HD + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            u32x4 w = *(const u32x4*)(qp + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pack2bf(bflo(w[j]) * sc, bfhi(w[j]) * sc);
+            qf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    f32x16 oacc[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float psum_limit = fast_exp2(p.rescale_thr);
+
+    u32x4 kreg[STG], vreg[STG];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < STG; ++i) {
+            const int idx = tid + NT * i;
+            int key = kv0 + (idx >> 4);
+            key = key < S ? key : S - 1;
+            kreg[i] = *(const u32x4*)(kbase + (size_t)key * p.ldk + (idx & 15) * 8);
+            vreg[i] = *(const u32x4*)(vbase + (size_t)key * p.ldk + (idx & 15) * 8);
+        }
+    };
+    auto write_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < STG; ++i) {
+            const int idx = tid + NT * i, key = idx >> 4, c = idx & 15;
+            *(u32x4*)(k_lds + key * PA_KROW + ((c ^ (key & 15)) * 16)) = kreg[i];  // 16 consecutive rows -> 16 distinct 16-B slots
+            *(u32x4*)(v_lds + key * PA_VROW + c * 16) = vreg[i];
+        }
+    };
+    // key tiles 0 .. the tile of the block's last (real) query
+    const int q_last = (q0 + NW * 32 - 1 < S ? q0 + NW * 32 - 1 : S - 1);
+    const int ntiles = q_last / 64 + 1;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * 64;
+        __syncthreads();  // previous tile's LDS reads are done
+        write_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(kv0 + 64);
+        if (kv0 > qw + 31 || qw >= S) continue;  // wave-uniform: every key of this tile is past the wave's queries (or the wave is padding)
+        const bool both_halves = kv0 + 32 <= qw + 31;
+        const bool diag = kv0 + 63 > qw;  // some (query, key) pairs of the tile are masked
+        f32x16 sa[2];
+        auto scores = [&](const float seed) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+                const int key = kb * 32 + r;
+                const char* krow = k_lds + key * PA_KROW;
+                const int sw = key & 15;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sa[kb][i] = seed;
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s8 + h) ^ sw) * 16));
+                    sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s8], sa[kb], 0, 0, 0);
+                }
+            }
+        };
+        auto mask = [&]() {
+            if (diag) {
+                const int qry = qw + r;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kv0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key > qry) sa[kb][i] = -INFINITY;  // (covers a skipped second half too: its registers are stale)
+                    }
+            }
+        };
+        scores(t == 0 ? 0.f : -m_run);
+        float psum = 0.f;
+        bool exact = t == 0;
+        if (!exact) {  // common form: the chain left s' - m, one v_exp + one v_add per score (see attn_kernel)
+            mask();
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = fast_exp2(sa[kb][i]);
+                    sa[kb][i] = e;
+                    psum += e;
+                }
+            }
+            exact = !__all(psum <= psum_limit);
+            if (exact) scores(0.f);
+        }
+        if (exact) {
+            mask();
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sa[kb][i]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(mx, m_run);  // finite from tile 0 on: key 0 is visible to every query
+            psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !both_halves) continue;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = fast_exp2(sa[kb][i] - m_new);
+                    sa[kb][i] = e;
+                    psum += e;
+                }
+            }
+            if (t > 0 && !__all(m_new == m_run)) {
+                const float alpha = fast_exp2(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+            }
+            m_run = m_new;
+        }
+        l_run += psum;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && !both_halves) continue;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int key_base = kb * 32 + 16 * s2;
+                if (kv0 + key_base > qw + 31) continue;  // wave-uniform: these 16 keys are past every query of the wave (P = 0)
+                const bf16x8 pf = pack8(sa[kb], 8 * s2);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const bf16x8 vf = load_vt_frag<true, false>(v_lds, key_base, db, lane, PA_VROW);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- output: transpose the wave's 32 x 128 tile through LDS: 16 B per lane, 256 B per row ----
+    __syncthreads();
+    if (qw >= S) return;
+    char* stg = smem + wave * (32 * 256);
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 o;
+            o[0] = pack2bf(oacc[db][4 * i + 0] * inv, oacc[db][4 * i + 1] * inv);
+            o[1] = pack2bf(oacc[db][4 * i + 2] * inv, oacc[db][4 * i + 3] * inv);
+            // d = 32 db + 8 i + 4 h + 0..3 of query r: 16-byte chunk 4 db + i, half h; chunks XOR-swizzled by the row
+            *(u32x2*)(stg + r * 256 + (((db * 4 + i) ^ (r & 15)) * 16) + 8 * h) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: in-wave ordering suffices
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int rr = (lane >> 4) + 4 * it, c = lane & 15;
+        const u32x4 v = *(const u32x4*)(stg + rr * 256 + ((c ^ (rr & 15)) * 16));
+        if (qw + rr < S) *(u32x4*)(p.out + (size_t)(qw + rr) * p.ldo + head * PA_HD + c * 8) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LanguageBind temporal attention (modeling_video.py:133-155): for each (clip, token, head) attend over the
 // clip's t = 8 frames. Four such 8x8 problems are packed block-diagonally into one 32x32 MFMA tile per wave
 // (off-diagonal blocks masked to -inf), so the whole sub-block costs 8 MFMAs per 4 problems.
@@ -780,6 +984,18 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     const int pad9 = (t32 + 8) / 9 * 9 - t32, pad8 = (t32 + 7) / 8 * 8 - t32;
     if (pad9 < pad8) return launch_attn_cfg<3, 3>(a, s);
     return launch_attn_cfg<4, 2>(a, s);
+}
+
+hipError_t launch_prefill_attention(const PrefillAttnArgs& a_in, hipStream_t s) {
+    if (a_in.S <= 0) return hipSuccess;
+    if (a_in.H <= 0 || a_in.Hkv <= 0 || a_in.H % a_in.Hkv != 0) return hipErrorInvalidValue;
+    if ((a_in.ldq | a_in.ldk | a_in.ldo) % 8 != 0 || a_in.kv_head_stride % 8 != 0) return hipErrorInvalidValue;
+    PrefillAttnArgs a = a_in;
+    a.rescale_thr = g_attn_rescale_thr.load(std::memory_order_relaxed);
+    constexpr int NW = 4;
+    const int nqb = (a.S + NW * 32 - 1) / (NW * 32);
+    hipLaunchKernelGGL(prefill_attn_kernel<NW>, dim3(nqb, a.H), dim3(NW * 64), 0, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {

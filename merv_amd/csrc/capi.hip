@@ -843,6 +843,22 @@ extern "C" int merv_prefill_rope_cache(void* q, const void* k, const void* v, vo
     return 0;
 }
 
+extern "C" int merv_prefill_attention(const void* q, const void* k, const void* v, void* out, int32_t S, int32_t H, int32_t Hkv,
+                                      int32_t hd, int32_t ldq, int32_t ldk, int64_t kv_head_stride, int32_t ldo, float scale,
+                                      void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && out, "merv_prefill_attention: null argument");
+    MERV_CHECK(hd == 128, "merv_prefill_attention: head_dim must be 128");
+    MERV_CHECK(S > 0 && H > 0 && Hkv > 0 && H % Hkv == 0, "merv_prefill_attention: bad geometry");
+    MERV_CHECK(ldq >= H * hd && ldo >= H * hd && ldk >= hd && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0 && kv_head_stride % 8 == 0,
+               "merv_prefill_attention: strides must cover the rows and be multiples of 8 elements");
+    MERV_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) == 0, "merv_prefill_attention: 16-byte alignment required");
+    PrefillAttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, S, H, Hkv, ldq, ldk, ldo, (long)kv_head_stride,
+                      scale, 0.f};
+    MERV_HIP(launch_prefill_attention(a, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int merv_silu_mul(const void* gate, const void* up, void* out, int64_t n, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(gate && up && out, "merv_silu_mul: null argument");

@@ -137,6 +137,19 @@ struct AttnArgs {
     int q_prescaled;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+// Causal attention of the LLM prompt prefill: head_dim 128, one sequence of S positions, GQA (kv head = head / (H / Hkv)).
+struct PrefillAttnArgs {
+    const bf16_t* q;     // [S, ldq], head h at columns [128 h, 128 h + 128) (rotary already applied)
+    const bf16_t* k;     // kv head g, position s at k + g * kv_head_stride + s * ldk (the KV cache: ldk = 128, stride = max_len * 128)
+    const bf16_t* v;
+    bf16_t* out;         // [S, ldo], same column layout as q
+    int S, H, Hkv;
+    int ldq, ldk, ldo;   // elements
+    long kv_head_stride; // elements
+    float scale;         // 1 / sqrt(128)
+    float rescale_thr;   // set by the launcher (see AttnArgs)
+};
+hipError_t launch_prefill_attention(const PrefillAttnArgs& a, hipStream_t s);
 void set_attn_rescale_thr(float thr);  // test / probe hook (default 8, or MERV_ATTN_RESCALE_THR read once per process)
 
 // LanguageBind temporal attention: for every (clip, token, head) an 8x8 attention over the clip's t frames.

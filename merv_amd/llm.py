@@ -445,6 +445,8 @@ class HipDecoder(StaticDecoder):
     # instead of ~35 PyTorch kernels per layer; same rounding points as `_layer`), the GEMMs and the causal attention on PyTorch-ROCm.
     # MERV_HIP_PREFILL=0 takes the plain PyTorch expression of StaticDecoder.
     use_hip_prefill = os.environ.get("MERV_HIP_PREFILL", "1") != "0"
+    # ... and the causal attention on merv_prefill_attention (head dim 128) instead of PyTorch-ROCm's SDPA; MERV_HIP_PREFILL_ATTN=0: SDPA
+    use_hip_prefill_attn = os.environ.get("MERV_HIP_PREFILL_ATTN", "1") != "0"
 
     @torch.inference_mode()
     def _prefill_fused(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
@@ -471,9 +473,14 @@ class HipDecoder(StaticDecoder):
                 v = F.linear(h, a.v_proj.weight, a.v_proj.bias)
                 check(lib.merv_prefill_rope_cache(ptr(q), ptr(k), ptr(v), ptr(self.K[li]), ptr(self.V[li]), ptr(self.cos), ptr(self.sin),
                                                   S, 0, H, Hkv, hd, self.max_len, st), "merv_prefill_rope_cache")
-                o = F.scaled_dot_product_attention(q.view(1, S, H, hd).transpose(1, 2), self.K[li][:, :, :S], self.V[li][:, :, :S],
-                                                   is_causal=True, enable_gqa=H != Hkv)
-                x += F.linear(o.transpose(1, 2).reshape(S, H * hd), a.o_proj.weight, a.o_proj.bias)
+                if self.use_hip_prefill_attn:  # causal attention straight off the cache rows, output in the o-projection's layout
+                    o = torch.empty_like(q)
+                    check(lib.merv_prefill_attention(ptr(q), ptr(self.K[li]), ptr(self.V[li]), ptr(o), S, H, Hkv, hd, H * hd, hd,
+                                                     self.max_len * hd, H * hd, hd**-0.5, st), "merv_prefill_attention")
+                else:
+                    o = F.scaled_dot_product_attention(q.view(1, S, H, hd).transpose(1, 2), self.K[li][:, :, :S], self.V[li][:, :, :S],
+                                                       is_causal=True, enable_gqa=H != Hkv).transpose(1, 2).reshape(S, H * hd)
+                x += F.linear(o, a.o_proj.weight, a.o_proj.bias)
                 rms(x, lyr.post_attention_layernorm.weight, h, S)
                 g = F.linear(h, mlp.gate_proj.weight)
                 u = F.linear(h, mlp.up_proj.weight)

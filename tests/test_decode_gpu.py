@@ -295,6 +295,34 @@ def test_prefill_rope_cache_rows(dev):
     assert torch.equal(Kc[:, keep], K0[:, keep]) and torch.equal(Vc[:, keep], V0[:, keep])
 
 
+@pytest.mark.parametrize("S,H,Hkv", [(1, 2, 2), (37, 4, 2), (128, 2, 1), (129, 2, 2), (449, 4, 4), (1049, 8, 2)])
+def test_prefill_attention_vs_sdpa(dev, S, H, Hkv):
+    """merv_prefill_attention (causal, head dim 128, K / V read from the cache layout, output in the o-projection's layout) against
+    F.scaled_dot_product_attention(is_causal=True) in fp32 on the same bf16 inputs."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(100 + S)
+    hd, max_len = 128, 1280
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    q = bf(torch.randn(S, H * hd, generator=g) * 1.5)
+    Kc, Vc = bf(torch.randn(Hkv, max_len, hd, generator=g)), bf(torch.randn(Hkv, max_len, hd, generator=g))
+    if S > 40:  # a query with one dominant late key and one with a dominant early key: the running maximum has to move / hold
+        q[S - 3, :hd] = (Kc[0, S - 5] * 0.6).to(q.dtype)
+        q[S // 2, :hd] = (Kc[0, 1] * 0.6).to(q.dtype)
+    out = torch.full((S, H * hd), float("nan"), dtype=torch.bfloat16, device=dev)
+    check(lib.merv_prefill_attention(ptr(q), ptr(Kc), ptr(Vc), ptr(out), S, H, Hkv, hd, H * hd, hd, max_len * hd, H * hd, hd**-0.5, _st(dev)),
+          "merv_prefill_attention")
+    qf = q.float().view(1, S, H, hd).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qf, Kc[None, :, :S].float(), Vc[None, :, :S].float(), is_causal=True, enable_gqa=H != Hkv)
+    ref = ref.transpose(1, 2).reshape(S, H * hd)
+    assert torch.isfinite(out.float()).all()
+    err = rel_l2(out, ref)
+    worst_row = float(((out.float() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-6)).max())
+    print(f"prefill attention S={S} H={H}/{Hkv}: rel-L2 {err:.3e}, worst row {worst_row:.3e}")
+    assert err < 8e-3 and worst_row < 3e-2
+
+
 def test_silu_mul(dev):
     """merv_silu_mul == F.silu(gate) * up on bf16 tensors (in place into gate as well)."""
     from merv_amd import _lib
