@@ -12,7 +12,7 @@ frames [16,16,32,16], bf16) on N MI355X. Contract: see the task statement; ONE J
                  projector's output and the fused [1,1024,4096] tokens (N = 1 only)
   cpu_baseline = the wall time of that same oracle run on this host's cores (no extrapolation)
   e2e          = BASELINE.json's secondary metric: quick_start-shaped generate() (GPU frame transforms -> visual path ->
-                 Llama-2-7B-geometry prefill on PyTorch-ROCm -> greedy decode on the HIP decode kernels), generated tokens / s
+                 Llama-2-7B-geometry prefill (library GEMMs + HIP kernels) -> greedy decode on the HIP decode kernels), generated tokens / s
                  (N = 1 only)
   multi_gpu    = N > 1: besides the data-parallel headline, the (encoder, video, frame-range) unit placement with both RCCL
                  exchanges timed in the same process group (BASELINE.json configs[2])
@@ -195,9 +195,12 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
         for _ in range(32):
             dec.decode(tok)
         torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
-    res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill on PyTorch-ROCm (SDPA), "
-                   f"decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 5 launches per layer" if type(dec).__name__ == "HipDecoder"
-                                                                else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
+    hip_prefill = type(dec).__name__ == "HipDecoder" and getattr(dec, "use_hip_prefill", False)
+    res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill: "
+                   + ("PyTorch-ROCm library GEMMs + libmerv_hip.so kernels for RMSNorm / rotary + cache fill / causal attention / silu * up"
+                      if hip_prefill else "PyTorch-ROCm (SDPA)") +
+                   f"; decode steps on {type(dec).__name__} (" + ("libmerv_hip.so decode kernels, 5 launches per layer" if type(dec).__name__ == "HipDecoder"
+                                                                 else "PyTorch-ROCm ops on a static cache, hipGraph-replayed") + ")",
            "new_tokens": int(out.shape[1]), "total_s": round(t, 4), "generated_tok_per_s": round(out.shape[1] / t, 2),
            "gpu_transforms_ms": round(t_pre * 1e3, 2), "visual_path_ms": round(t_enc * 1e3, 2), "prefill_tokens": n_pre,
            "prefill_ms": round(t_prefill * 1e3, 2), "decode_ms_per_token": round(t_dec * 1e3, 3)}

@@ -340,6 +340,8 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
  *  merv_prefill_rope_cache  apply_rotary_pos_emb on positions pos0 .. pos0 + S - 1: q [S, H*hd] rotated IN PLACE, rot(k [S, Hkv*hd]) ->
  *                           k_cache[:, pos0 + s], v -> v_cache[:, pos0 + s]; caches [Hkv, max_len, hd], tables [max_len, hd]; hd % 16 == 0
  *  merv_silu_mul            out = bf16(bf16(silu(gate)) * up), n elements (n % 8 == 0); out may alias gate or up
+ *  merv_add_rmsnorm         the residual add and the next RMSNorm in one pass: x <- bf16(x + delta) IN PLACE, y = RMSNorm(x) (same bits
+ *                           as the add followed by merv_decode_rmsnorm); x, delta, y [rows, D], D <= 8192
  *  merv_prefill_attention   causal softmax(q k^T * scale) v of ONE sequence of S positions, hd = 128, GQA (kv head = h / (H / Hkv)):
  *                           replaces F.scaled_dot_product_attention(q, k, v, is_causal=True) of LlamaAttention.forward on the prompt.
  *                           q [S, ldq] (head h at columns 128 h ..; rotary applied), k / v: kv head g, position s at
@@ -348,6 +350,7 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
 int merv_prefill_rope_cache(void *q, const void *k, const void *v, void *k_cache, void *v_cache, const void *cos_t, const void *sin_t,
                             int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, void *stream);
 int merv_silu_mul(const void *gate, const void *up, void *out, int64_t n, void *stream);
+int merv_add_rmsnorm(void *x, const void *delta, const void *w, void *y, int32_t rows, int32_t D, float eps, void *stream);
 int merv_prefill_attention(const void *q, const void *k, const void *v, void *out, int32_t S, int32_t H, int32_t Hkv, int32_t hd,
                            int32_t ldq, int32_t ldk, int64_t kv_head_stride, int32_t ldo, float scale, void *stream);
 /* three projections of the same input in one launch (q_proj / k_proj / v_proj): y_i[N_i] = bf16(W_i[N_i,K] x[K]) */

@@ -113,6 +113,7 @@ SIGNATURES = {
     "merv_decode_rope_cache": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_prefill_rope_cache": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "merv_silu_mul": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "merv_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "merv_prefill_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int64, _i32, _f32, _vp]),
     "merv_decode_attention_workspace_floats": (_sz, [_i32, _i32]),
     "merv_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -843,6 +843,15 @@ extern "C" int merv_prefill_rope_cache(void* q, const void* k, const void* v, vo
     return 0;
 }
 
+extern "C" int merv_add_rmsnorm(void* x, const void* delta, const void* w, void* y, int32_t rows, int32_t D, float eps, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(x && delta && w && y, "merv_add_rmsnorm: null argument");
+    MERV_CHECK(rows > 0 && D > 0 && D % 8 == 0 && D <= 8192, "merv_add_rmsnorm: rows > 0, D % 8 == 0 and D <= 8192 required");
+    DecodeRmsArgs a{(const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, rows, D, eps};
+    MERV_HIP(launch_add_rmsnorm(a, (const bf16_t*)delta, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int merv_prefill_attention(const void* q, const void* k, const void* v, void* out, int32_t S, int32_t H, int32_t Hkv,
                                       int32_t hd, int32_t ldq, int32_t ldk, int64_t kv_head_stride, int32_t ldo, float scale,
                                       void* stream_) {

@@ -92,6 +92,56 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(DecodeRmsArgs p) {
     }
 }
 
+// ---- prompt prefill: residual add + RMSNorm of the sum in one pass (x <- bf16(x + delta); y = RMSNorm(x)): one BLOCK per row ----
+// Wave w takes part w of the row (chunks lane + 64 w + 256 i, as sumsq_part) and the four parts meet in LDS, so the mean of squares is
+// formed exactly as rmsnorm_kernel forms it on the updated row -- from registers instead of a second read. D <= 8192.
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(DecodeRmsArgs p, const bf16_t* delta) {
+    __shared__ float part_ss[4];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int row = blockIdx.x;
+    bf16_t* x = const_cast<bf16_t*>(p.x) + (size_t)row * p.D;
+    const bf16_t* d = delta + (size_t)row * p.D;
+    const int nchunk = p.D >> 3;
+    u32x4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * part + 256 * i;
+        v[i] = u32x4{0u, 0u, 0u, 0u};
+        if (c < nchunk) {
+            float a[8], b[8];
+            unpack8f(*(const u32x4*)(x + c * 8), a);
+            unpack8f(*(const u32x4*)(d + c * 8), b);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[i][q] = pack2bf(a[2 * q] + b[2 * q], a[2 * q + 1] + b[2 * q + 1]);
+            *(u32x4*)(x + c * 8) = v[i];
+        }
+        float f[8];
+        unpack8f(v[i], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ss = fmaf(f[q], f[q], ss);  // (a zero chunk adds exactly nothing)
+    }
+    ss = wave_sum64(ss);
+    if (lane == 0) part_ss[part] = ss;
+    __syncthreads();
+    const float tot = ((part_ss[0] + part_ss[1]) + part_ss[2]) + part_ss[3];
+    const float rstd = rsqrtf(tot / (float)p.D + p.eps);
+    bf16_t* y = p.y + (size_t)row * p.D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * part + 256 * i;
+        if (c < nchunk) {
+            float f[8], w[8];
+            unpack8f(v[i], f);
+            unpack8f(*(const u32x4*)(p.w + c * 8), w);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack2bf(w[2 * q] * round_bf(f[2 * q] * rstd), w[2 * q + 1] * round_bf(f[2 * q + 1] * rstd));
+            *(u32x4*)(y + c * 8) = o;
+        }
+    }
+}
+
 // ---- hand-off policies: how a kernel body meets the data other workgroups produce / consume ----
 // Stand-alone launches: inputs are complete before the launch starts and outputs are read after it ends.
 struct NoHandoff {
@@ -880,6 +930,13 @@ hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
     if (a.rows <= 0) return hipSuccess;
     if (a.D % 8 != 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rmsnorm_kernel, dim3((a.rows + 3) / 4), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_rmsnorm(const DecodeRmsArgs& a, const bf16_t* delta, hipStream_t s) {
+    if (a.rows <= 0) return hipSuccess;
+    if (a.D % 8 != 0 || a.D > 8192) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(a.rows), dim3(256), 0, s, a, delta);
     return hipGetLastError();
 }
 

@@ -304,6 +304,8 @@ struct DecodeRmsArgs {   // LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps
     float eps;
 };
 hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s);
+// x <- bf16(x + delta) in place (a.x is written), y = RMSNorm of the updated rows; D <= 8192
+hipError_t launch_add_rmsnorm(const DecodeRmsArgs& a, const bf16_t* delta, hipStream_t s);
 
 struct DecodeGemvArgs {  // y = bf16(W x) (+ res), or with W2: y = silu(bf16(W x)) * bf16(W2 x); x [K], y [N]
     // up to three matrices that share x in ONE launch (q / k / v projections): rows [0, N) belong to W / y, rows

@@ -465,9 +465,14 @@ class HipDecoder(StaticDecoder):
             def rms(src, w, dst, rows):
                 check(lib.merv_decode_rmsnorm(ptr(src), ptr(w), ptr(dst), rows, D, self.eps, st), "merv_decode_rmsnorm")
 
-            for li, lyr in enumerate(m.model.layers):
+            def add_rms(delta, w):  # x += delta; h = RMSNorm(x) * w, one pass
+                check(lib.merv_add_rmsnorm(ptr(x), ptr(delta), ptr(w), ptr(h), S, D, self.eps, st), "merv_add_rmsnorm")
+
+            fuse_add = D <= 8192
+            layers = m.model.layers
+            rms(x, layers[0].input_layernorm.weight, h, S)
+            for li, lyr in enumerate(layers):
                 a, mlp = lyr.self_attn, lyr.mlp
-                rms(x, lyr.input_layernorm.weight, h, S)
                 q = F.linear(h, a.q_proj.weight, a.q_proj.bias)
                 k = F.linear(h, a.k_proj.weight, a.k_proj.bias)
                 v = F.linear(h, a.v_proj.weight, a.v_proj.bias)
@@ -480,12 +485,23 @@ class HipDecoder(StaticDecoder):
                 else:
                     o = F.scaled_dot_product_attention(q.view(1, S, H, hd).transpose(1, 2), self.K[li][:, :, :S], self.V[li][:, :, :S],
                                                        is_causal=True, enable_gqa=H != Hkv).transpose(1, 2).reshape(S, H * hd)
-                x += F.linear(o, a.o_proj.weight, a.o_proj.bias)
-                rms(x, lyr.post_attention_layernorm.weight, h, S)
+                o = F.linear(o, a.o_proj.weight, a.o_proj.bias)
+                if fuse_add:
+                    add_rms(o, lyr.post_attention_layernorm.weight)
+                else:
+                    x += o
+                    rms(x, lyr.post_attention_layernorm.weight, h, S)
                 g = F.linear(h, mlp.gate_proj.weight)
                 u = F.linear(h, mlp.up_proj.weight)
                 check(lib.merv_silu_mul(ptr(g), ptr(u), ptr(g), S * I, st), "merv_silu_mul")
-                x += F.linear(g, mlp.down_proj.weight)
+                dn = F.linear(g, mlp.down_proj.weight)
+                if li + 1 == len(layers):
+                    x += dn  # only the last row goes through the final norm below
+                elif fuse_add:
+                    add_rms(dn, layers[li + 1].input_layernorm.weight)
+                else:
+                    x += dn
+                    rms(x, layers[li + 1].input_layernorm.weight, h, S)
             if not hasattr(self, "pos"):
                 self.pos = torch.tensor([S], device=self.dev)
             else:

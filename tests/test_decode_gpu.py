@@ -323,6 +323,23 @@ def test_prefill_attention_vs_sdpa(dev, S, H, Hkv):
     assert err < 8e-3 and worst_row < 3e-2
 
 
+@pytest.mark.parametrize("rows,D", [(5, 256), (77, 4096), (9, 5120), (3, 8192)])
+def test_add_rmsnorm_equals_add_then_rmsnorm(dev, rows, D):
+    """merv_add_rmsnorm == (x + delta in bf16) followed by merv_decode_rmsnorm, bit for bit; x is updated in place."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows + D)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    x, d, w = bf(torch.randn(rows, D, generator=g)), bf(torch.randn(rows, D, generator=g) * 0.3), bf(torch.randn(D, generator=g))
+    xs = x + d
+    y_ref = torch.empty_like(xs)
+    check(lib.merv_decode_rmsnorm(ptr(xs), ptr(w), ptr(y_ref), rows, D, 1e-5, _st(dev)), "rmsnorm")
+    y = torch.empty_like(x)
+    check(lib.merv_add_rmsnorm(ptr(x), ptr(d), ptr(w), ptr(y), rows, D, 1e-5, _st(dev)), "add_rmsnorm")
+    assert torch.equal(x, xs) and torch.equal(y, y_ref)
+
+
 def test_silu_mul(dev):
     """merv_silu_mul == F.silu(gate) * up on bf16 tensors (in place into gate as well)."""
     from merv_amd import _lib
