@@ -337,8 +337,9 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
 /* Prompt prefill (batch 1; S positions at once) -- the elementwise parts of a decoder layer between the library GEMMs, each one launch
  * instead of the 5-10 PyTorch kernels of the module's expression (same rounding points; merv/models/vidlms/merv.py:723-734 ->
  * LlamaDecoderLayer.forward): merv_decode_rmsnorm takes rows = S; these two do the rest.
- *  merv_prefill_rope_cache  apply_rotary_pos_emb on positions pos0 .. pos0 + S - 1: q [S, H*hd] rotated IN PLACE, rot(k [S, Hkv*hd]) ->
- *                           k_cache[:, pos0 + s], v -> v_cache[:, pos0 + s]; caches [Hkv, max_len, hd], tables [max_len, hd]; hd % 16 == 0
+ *  merv_prefill_rope_cache  apply_rotary_pos_emb on positions pos0 .. pos0 + S - 1: q [S, ldq] (H*hd columns) rotated IN PLACE,
+ *                           rot(k [S, ldk]) -> k_cache[:, pos0 + s], v [S, ldk] -> v_cache[:, pos0 + s] (q / k / v may be column ranges of
+ *                           one projection output); caches [Hkv, max_len, hd], tables [max_len, hd]; hd % 16 == 0
  *  merv_silu_mul            out = bf16(bf16(silu(gate)) * up), n elements (n % 8 == 0); out may alias gate or up
  *  merv_add_rmsnorm         the residual add and the next RMSNorm in one pass: x <- bf16(x + delta) IN PLACE, y = RMSNorm(x) (same bits
  *                           as the add followed by merv_decode_rmsnorm); x, delta, y [rows, D], D <= 8192
@@ -348,7 +349,8 @@ int merv_decode_rope_cache(const void *q, const void *k, const void *v, void *q_
  *                           base + g * kv_head_stride + s * ldk (the KV cache itself: ldk = 128, kv_head_stride = max_len * 128),
  *                           out [S, ldo] in q's column layout -- the o-projection's input, no transpose */
 int merv_prefill_rope_cache(void *q, const void *k, const void *v, void *k_cache, void *v_cache, const void *cos_t, const void *sin_t,
-                            int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, void *stream);
+                            int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len, int32_t ldq, int32_t ldk,
+                            void *stream);
 int merv_silu_mul(const void *gate, const void *up, void *out, int64_t n, void *stream);
 int merv_add_rmsnorm(void *x, const void *delta, const void *w, void *y, int32_t rows, int32_t D, float eps, void *stream);
 int merv_prefill_attention(const void *q, const void *k, const void *v, void *out, int32_t S, int32_t H, int32_t Hkv, int32_t hd,

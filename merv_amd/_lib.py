@@ -111,7 +111,7 @@ SIGNATURES = {
     "merv_decode_gemv3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
     "merv_decode_gemv3_bias": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp, _vp, _vp]),
     "merv_decode_rope_cache": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "merv_prefill_rope_cache": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "merv_prefill_rope_cache": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "merv_silu_mul": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "merv_add_rmsnorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp]),
     "merv_prefill_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int64, _i32, _f32, _vp]),

@@ -832,13 +832,15 @@ extern "C" int merv_decode_rope_cache(const void* q, const void* k, const void* 
 
 extern "C" int merv_prefill_rope_cache(void* q, const void* k, const void* v, void* k_cache, void* v_cache, const void* cos_t,
                                        const void* sin_t, int32_t S, int32_t pos0, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
-                                       void* stream_) {
+                                       int32_t ldq, int32_t ldk, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(q && k && v && k_cache && v_cache && cos_t && sin_t, "merv_prefill_rope_cache: null argument");
     MERV_CHECK(S > 0 && pos0 >= 0 && H > 0 && Hkv > 0 && hd > 0 && hd % 16 == 0 && max_len > 0 && pos0 + S <= max_len,
                "merv_prefill_rope_cache: bad geometry (hd % 16 == 0, pos0 + S <= max_len required)");
+    MERV_CHECK(ldq >= H * hd && ldk >= Hkv * hd && ldq % 8 == 0 && ldk % 8 == 0, "merv_prefill_rope_cache: row strides must cover the rows, multiples of 8");
+    MERV_CHECK((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0, "merv_prefill_rope_cache: 16-byte alignment required");
     PrefillRopeArgs a{(bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)k_cache, (bf16_t*)v_cache, (const bf16_t*)cos_t,
-                      (const bf16_t*)sin_t, S, pos0, H, Hkv, hd, max_len};
+                      (const bf16_t*)sin_t, S, pos0, H, Hkv, hd, max_len, ldq, ldk};
     MERV_HIP(launch_prefill_rope_cache(a, (hipStream_t)stream_));
     return 0;
 }

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void prefill_rope_cache_kernel(PrefillRopeArgs
         if (it < (p.H + p.Hkv) * hc) {
             const int head = it / hc, d0 = (it - head * hc) * 8, half = p.hd >> 1;
             const bool is_q = head < p.H;
-            const bf16_t* src = is_q ? p.q + ((size_t)s * p.H + head) * p.hd : p.k + ((size_t)s * p.Hkv + (head - p.H)) * p.hd;
+            const bf16_t* src = is_q ? p.q + (size_t)s * p.ldq + head * p.hd : p.k + (size_t)s * p.ldk + (head - p.H) * p.hd;
             float lo[8], hi[8], cl[8], ch[8], sl[8], sh[8];
             unpack8f(*(const u32x4*)(src + d0), lo);
             unpack8f(*(const u32x4*)(src + d0 + half), hi);
@@ -438,13 +438,13 @@ __global__ __launch_bounds__(256) void prefill_rope_cache_kernel(PrefillRopeArgs
                 olo[j] = pack2bf(round_bf(lo[a] * cl[a]) + round_bf(-hi[a] * sl[a]), round_bf(lo[b] * cl[b]) + round_bf(-hi[b] * sl[b]));
                 ohi[j] = pack2bf(round_bf(hi[a] * ch[a]) + round_bf(lo[a] * sh[a]), round_bf(hi[b] * ch[b]) + round_bf(lo[b] * sh[b]));
             }
-            bf16_t* dst = is_q ? p.q + ((size_t)s * p.H + head) * p.hd : p.k_cache + ((size_t)(head - p.H) * p.max_len + pos) * p.hd;
+            bf16_t* dst = is_q ? p.q + (size_t)s * p.ldq + head * p.hd : p.k_cache + ((size_t)(head - p.H) * p.max_len + pos) * p.hd;
             *(u32x4*)(dst + d0) = olo;
             *(u32x4*)(dst + d0 + half) = ohi;
         } else {
             it -= (p.H + p.Hkv) * hc;
             const int hv = it / (2 * hc), d0 = (it - hv * 2 * hc) * 8;
-            *(u32x4*)(p.v_cache + ((size_t)hv * p.max_len + pos) * p.hd + d0) = *(const u32x4*)(p.v + ((size_t)s * p.Hkv + hv) * p.hd + d0);
+            *(u32x4*)(p.v_cache + ((size_t)hv * p.max_len + pos) * p.hd + d0) = *(const u32x4*)(p.v + (size_t)s * p.ldk + hv * p.hd + d0);
         }
     }
 }
@@ -993,6 +993,7 @@ hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s) {
 hipError_t launch_prefill_rope_cache(const PrefillRopeArgs& a, hipStream_t s) {
     if (a.S <= 0) return hipSuccess;
     if (a.hd % 16 != 0 || a.H <= 0 || a.Hkv <= 0 || a.pos0 < 0 || a.pos0 + a.S > a.max_len) return hipErrorInvalidValue;
+    if (a.ldq < a.H * a.hd || a.ldk < a.Hkv * a.hd || (a.ldq | a.ldk) % 8 != 0) return hipErrorInvalidValue;
     const long total = (long)a.S * ((a.H + a.Hkv) * (a.hd / 16) + a.Hkv * (a.hd / 8));
     const long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(prefill_rope_cache_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, a);

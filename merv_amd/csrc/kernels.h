@@ -351,14 +351,15 @@ hipError_t launch_decode_rope_cache(const DecodeRopeArgs& a, hipStream_t s);
 
 // Prompt prefill (batch 1, S positions at once) around the library GEMMs: the elementwise parts of a decoder layer.
 struct PrefillRopeArgs {  // apply_rotary_pos_emb on S positions + cache fill: q rotated in place, cache[:, pos0 + s] <- rot(k), v
-    bf16_t* q;           // [S, H * hd]
-    const bf16_t* k;     // [S, Hkv * hd]
-    const bf16_t* v;     // [S, Hkv * hd]
+    bf16_t* q;           // [S, ldq], H * hd columns used
+    const bf16_t* k;     // [S, ldk], Hkv * hd columns used
+    const bf16_t* v;     // [S, ldk]
     bf16_t* k_cache;     // [Hkv, max_len, hd]
     bf16_t* v_cache;
     const bf16_t* cos;   // [max_len, hd]
     const bf16_t* sin;
     int S, pos0, H, Hkv, hd, max_len;
+    int ldq, ldk;        // row strides in elements (q, k and v may be column ranges of one [S, (H + 2 Hkv) * hd] projection output)
 };
 hipError_t launch_prefill_rope_cache(const PrefillRopeArgs& a, hipStream_t s);
 struct SiluMulArgs {     // LlamaMLP's act_fn(gate) * up on materialised bf16 tensors: out = bf16(bf16(silu(gate)) * up)

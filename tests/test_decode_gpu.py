@@ -287,8 +287,15 @@ def test_prefill_rope_cache_rows(dev):
     Kc = bf(torch.randn(Hkv, max_len, hd, generator=g))
     Vc = bf(torch.randn(Hkv, max_len, hd, generator=g))
     K0, V0 = Kc.clone(), Vc.clone()
-    check(lib.merv_prefill_rope_cache(ptr(q), ptr(k), ptr(v), ptr(Kc), ptr(Vc), ptr(cos), ptr(sin), S, pos0, H, Hkv, hd, max_len, _st(dev)), "rope")
+    qkv = torch.cat([q, k, v], 1).contiguous()  # the same through column ranges of one [S, (H + 2 Hkv) * hd] buffer
+    check(lib.merv_prefill_rope_cache(ptr(q), ptr(k), ptr(v), ptr(Kc), ptr(Vc), ptr(cos), ptr(sin), S, pos0, H, Hkv, hd, max_len,
+                                      H * hd, Hkv * hd, _st(dev)), "rope")
     assert torch.equal(q.view(S, H, hd), q_ref)
+    K2, V2 = K0.clone(), V0.clone()
+    ld = (H + 2 * Hkv) * hd
+    check(lib.merv_prefill_rope_cache(ptr(qkv), qkv.data_ptr() + 2 * H * hd, qkv.data_ptr() + 2 * (H + Hkv) * hd, ptr(K2), ptr(V2), ptr(cos),
+                                      ptr(sin), S, pos0, H, Hkv, hd, max_len, ld, ld, _st(dev)), "rope strided")
+    assert torch.equal(qkv[:, :H * hd], q) and torch.equal(K2, Kc) and torch.equal(V2, Vc)
     assert torch.equal(Kc[:, pos0:pos0 + S], k_ref.transpose(0, 1)) and torch.equal(Vc[:, pos0:pos0 + S], v.view(S, Hkv, hd).transpose(0, 1))
     keep = torch.ones(max_len, dtype=torch.bool)
     keep[pos0:pos0 + S] = False
@@ -381,7 +388,23 @@ def test_hip_prefill_matches_pytorch_prefill(dev, kv_heads, family):
     assert hip.use_hip_prefill
     emb = (torch.randn(1, 77, 256, generator=torch.Generator().manual_seed(4)) * 0.5).to(torch.bfloat16).to(dev)
     emb0 = emb.clone()
+    sd0 = {k: v.clone() for k, v in llm.llm.state_dict().items()}
     l_ref, l_hip = ref.prefill(emb), hip.prefill(emb)
+    # the q / k / v parameters now live in one fused matrix per layer (one GEMM): same values, contiguous, still ordinary tensors
+    for k, v in llm.llm.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    a0 = llm.llm.model.layers[0].self_attn
+    assert a0.k_proj.weight.data_ptr() == a0.q_proj.weight.data_ptr() + a0.q_proj.weight.numel() * 2
+    assert a0.v_proj.weight.data_ptr() == a0.k_proj.weight.data_ptr() + a0.k_proj.weight.numel() * 2
+    assert not a0.q_proj.weight.is_inference() and a0.q_proj.weight.is_contiguous()
+    with torch.no_grad():  # an in-place load reaches the fused matrix; a replaced storage is noticed and fused again
+        a0.q_proj.weight.mul_(1.0)
+    fused_before = a0._merv_qkv[0]
+    hip.prefill(emb)
+    assert a0._merv_qkv[0] is fused_before
+    a0.k_proj.weight.data = a0.k_proj.weight.data.clone()
+    l_again = hip.prefill(emb)
+    assert a0._merv_qkv[0] is not fused_before and torch.equal(l_again, l_hip)
     assert torch.equal(emb, emb0)  # the caller's embeddings are not the in-place residual stream
     assert int(hip.pos) == 77 == int(ref.pos)
     assert rel_l2(l_hip, l_ref) < 2e-2
