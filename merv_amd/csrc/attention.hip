@@ -818,24 +818,47 @@ __global__ __launch_bounds__(NH > 4 ? NH * 64 : 256) void temporal_attn_kernel(T
         return (size_t)(clip * 8 + (idx & 7)) * p.ntok + tok;
     };
     const size_t my_row = row_of(r);
-    const bf16_t* qrow = p.qkv + my_row * ld + head * HD;
 
     bf16x8 qf[4], kf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = *(const bf16x8*)(qrow + 16 * s + 8 * h);
-        kf[s] = *(const bf16x8*)(qrow + D + 16 * s + 8 * h);
-    }
-    // stage this wave's 32 V rows
     if constexpr (VTR) {
+        // Every global access is 8 lanes x 16 B = one 128-byte head segment of a row (round 4; the fragment-shaped loads were 32-byte
+        // pieces of 32 different rows per instruction). q, k and v rows arrive in registers in that shape; q and k then pass through
+        // the wave's LDS region one after the other (chunks XOR-swizzled by the row, as the K tiles of attn_kernel) to be read back
+        // as MFMA fragments, and the region finally holds the V image. Wave-private: in-wave ordering (lgkmcnt) is enough.
+        u32x4 raw[3][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i;
-            const int row = idx >> 3, c = idx & 7;
-            const u32x4 v = *(const u32x4*)(p.qkv + row_of(row) * ld + 2 * D + head * HD + c * 8);
-            *(u32x4*)(v_lds + row * TV_ROW_TR + c * 16) = v;
+            const bf16_t* src = p.qkv + row_of(idx >> 3) * ld + head * HD + (idx & 7) * 8;
+            raw[0][i] = *(const u32x4*)src;
+            raw[1][i] = *(const u32x4*)(src + D);
+            raw[2][i] = *(const u32x4*)(src + 2 * D);
+        }
+        auto through_lds = [&](const u32x4(&rw)[4], bf16x8(&frag)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 3, c = idx & 7;
+                *(u32x4*)(v_lds + row * 128 + ((c ^ kswz(row)) * 16)) = rw[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; ++s) frag[s] = *(const bf16x8*)(v_lds + r * 128 + (((2 * s + h) ^ kswz(r)) * 16));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // read back before the region is overwritten
+        };
+        through_lds(raw[0], qf);
+        through_lds(raw[1], kf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i;
+            *(u32x4*)(v_lds + (idx >> 3) * TV_ROW_TR + (idx & 7) * 16) = raw[2][i];
         }
     } else {
+        const bf16_t* qrow = p.qkv + my_row * ld + head * HD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *(const bf16x8*)(qrow + 16 * s + 8 * h);
+            kf[s] = *(const bf16x8*)(qrow + D + 16 * s + 8 * h);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int kp = (lane >> 3) + 8 * i, c = lane & 7;
@@ -914,6 +937,25 @@ __global__ __launch_bounds__(NH > 4 ? NH * 64 : 256) void temporal_attn_kernel(T
                         mx_pack4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3], inv);
                 if (h == 0) p.mx_scales[mx_scale_offset((int)my_row, col0 >> 5, p.mx_groups)] = (uint8_t)(e + 127);
             }
+        }
+    } else if constexpr (VTR) {
+        // transpose the wave's 32 x 64 result through its LDS region (the V image is consumed): stores of 16 B per lane, 128 B per row
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x2 o;
+                o[0] = pack2bf(oacc[db][4 * i + 0], oacc[db][4 * i + 1]);
+                o[1] = pack2bf(oacc[db][4 * i + 2], oacc[db][4 * i + 3]);
+                *(u32x2*)(v_lds + r * 128 + (((db * 4 + i) ^ (r & 7)) * 16) + 8 * h) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rr = (lane >> 3) + 8 * it, c = lane & 7;
+            const u32x4 v = *(const u32x4*)(v_lds + rr * 128 + ((c ^ (rr & 7)) * 16));
+            if (pid0 + (rr >> 3) < NP) *(u32x4*)(p.out + row_of(rr) * D + head * HD + c * 8) = v;
         }
     } else if (pid0 + myp < NP) {
         bf16_t* orow = p.out + my_row * D + head * HD;

@@ -217,7 +217,9 @@ def test_temporal_attention(dev, vtr, nclips, ntok, heads):
 
 
 @pytest.mark.parametrize("layout,patch,tub,frames,dtype", [("BFCHW", 16, 1, 2, torch.float32), ("BCFHW", 14, 1, 3, torch.float32),
-                                                           ("BFCHW", 16, 2, 4, torch.bfloat16)])
+                                                           ("BFCHW", 16, 2, 4, torch.bfloat16), ("BFCHW", 14, 1, 3, torch.bfloat16),
+                                                           ("BCFHW", 16, 1, 2, torch.bfloat16), ("BFCHW", 16, 2, 4, torch.float32),
+                                                           ("BFCHW", 32, 1, 2, torch.bfloat16), ("BFCHW", 8, 2, 2, torch.float32)])
 def test_im2col(dev, layout, patch, tub, frames, dtype):
     from merv_amd import ops
     B, img = 2, 224
