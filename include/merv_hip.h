@@ -294,6 +294,10 @@ int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t
  * the next GEMM. */
 int merv_debug_gemm_stats(const void *A, const void *W, void *C, const float *bias, const float *lscale, const void *res,
                           int32_t M, int32_t N, int32_t K, int32_t act, float *stats_out, void *stream);
+/* test hook: C = bf16(bf16(A W^T + bias + res) + row_add[(m / row_add_div) % row_add_mod]) (row_add fp32 [row_add_mod, N]; the form
+ * LanguageBind's fc2 uses to add the next block's temporal embedding) + the LayerNorm partials of the result */
+int merv_debug_gemm_row_add(const void *A, const void *W, void *C, const float *bias, const void *res, int32_t M, int32_t N, int32_t K,
+                            const float *row_add, int32_t row_add_div, int32_t row_add_mod, float *stats_out, void *stream);
 
 /*
  * Per-launch HIP-event timing (bench.py roofline leg). While a class (bit of `class_mask`) is enabled every launch of it is

@@ -71,9 +71,9 @@ struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + b
     const uint8_t *tqkv_q, *tqkv_s, *tproj_q, *tproj_s;  // LanguageBind temporal sub-block (null otherwise)
 };
 
-struct FoldLayer {  // LN1 folded into qkv, LN2 into fc1: bf16(W * gamma), sum_k of it, W.beta + bias
-    const bf16_t *qkv_w, *fc1_w;
-    const float *qkv_cs, *qkv_db, *fc1_cs, *fc1_db;
+struct FoldLayer {  // LN1 folded into qkv, LN2 into fc1 (LanguageBind: the temporal LayerNorm into the temporal qkv): bf16(W * gamma), sum_k of it, W.beta + bias
+    const bf16_t *qkv_w, *fc1_w, *tqkv_w;
+    const float *qkv_cs, *qkv_db, *fc1_cs, *fc1_db, *tqkv_cs, *tqkv_db;
 };
 
 struct merv_encoder {
@@ -202,7 +202,8 @@ static size_t fold_weight_bytes(int N, int K) { return align_up((size_t)N * K * 
 
 extern "C" size_t merv_encoder_ln_fold_bytes(const merv_encoder* e) {
     if (!e) return 0;
-    return (size_t)e->d.layers * (fold_weight_bytes(3 * e->d.dim, e->d.dim) + fold_weight_bytes(e->d.mlp_dim, e->d.dim));
+    return (size_t)e->d.layers * ((e->d.temporal_frames > 0 ? 2 : 1) * fold_weight_bytes(3 * e->d.dim, e->d.dim) +
+                                  fold_weight_bytes(e->d.mlp_dim, e->d.dim));
 }
 
 extern "C" int merv_encoder_enable_ln_fold(merv_encoder* e, void* buf, size_t bytes, void* stream_) {
@@ -230,6 +231,8 @@ extern "C" int merv_encoder_enable_ln_fold(merv_encoder* e, void* buf, size_t by
         FoldLayer& f = e->fl[i];
         MERV_HIP(fold(L.qkv_w, L.ln1_w, L.ln1_b, L.qkv_b, 3 * D, D, f.qkv_w, f.qkv_cs, f.qkv_db, D, ATTN_SCALE * 1.4426950408889634f));
         MERV_HIP(fold(L.fc1_w, L.ln2_w, L.ln2_b, L.fc1_b, H, D, f.fc1_w, f.fc1_cs, f.fc1_db, 0, 1.0f));
+        if (e->d.temporal_frames > 0)  // (the temporal attention kernel applies its own scale)
+            MERV_HIP(fold(L.t_qkv_w, L.t_ln_w, L.t_ln_b, L.t_qkv_b, 3 * D, D, f.tqkv_w, f.tqkv_cs, f.tqkv_db, 0, 1.0f));
     }
     e->fold = true;
     return 0;
@@ -384,16 +387,27 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     // does a folded LayerNorm read x right after the GEMM that writes it here? (then that GEMM produces the partials)
     static const bool fused_stats = !(getenv("MERV_LN_FUSED_STATS") && getenv("MERV_LN_FUSED_STATS")[0] == '0');  // A/B hook
     const bool fold_qkv = e->fold && !mx_qkv && fused_stats, fold_fc1 = e->fold && !mx_fc1 && fused_stats;
+    // LanguageBind: the temporal LayerNorm of blocks 1 .. folds into the temporal qkv GEMM as well -- the previous block's fc2 epilogue
+    // adds this block's temporal embedding into x (GemmArgs::row_add) and leaves the statistics partials, so no kernel re-reads x.
+    // Block 0 keeps the LayerNorm kernel (its x comes from the embedding / pre-LayerNorm).
+    static const bool fold_t_env = !(getenv("MERV_LN_FOLD_TEMPORAL") && getenv("MERV_LN_FOLD_TEMPORAL")[0] == '0');  // A/B hook
+    const bool fold_tqkv = fold_qkv && d.temporal_frames > 0 && ntok >= 256 && fold_t_env;
 
     // ---- transformer blocks ----
     for (int li = 0; li < d.layers; ++li) {
         const merv_layer_weights& L = e->layers[li];
         if (d.temporal_frames > 0) {
             // x += temporal_embedding[t]; x += out_proj(temporal_attn(LN_t(x)))   (modeling_video.py:133-155)
-            LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
-            if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
-            MERV_HIP(launch_layernorm(ln, s));
             GemmArgs q = gemm_args(ws.y, D, L.t_qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.t_qkv_b, ACT_NONE);
+            if (fold_tqkv && li > 0) {  // x already carries temporal_embedding (previous fc2) and its partials are in ws.parts
+                MERV_HIP(ln_stats());
+                q.A = ws.x; q.W = e->fl[li].tqkv_w; q.bias = e->fl[li].tqkv_db;
+                q.row_stats = ws.stats; q.ln_colsum = e->fl[li].tqkv_cs;
+            } else {
+                LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
+                if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
+                MERV_HIP(launch_layernorm(ln, s));
+            }
             if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
             else MERV_HIP(launch_gemm(q, s));
             TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
@@ -450,8 +464,11 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
             // the next reader of x is the following block's LN1 -- unless that block starts with the temporal sub-block
             // (its LayerNorm kernel first adds the temporal embedding into x) or this was the last block
-            const bool next_ln1 = fold_qkv && d.temporal_frames == 0 && li + 1 < d.layers;
+            const bool next_ln1 = fold_qkv && li + 1 < d.layers && (d.temporal_frames == 0 || fold_tqkv);
             if (next_ln1) f2.stats_out = ws.parts;
+            if (next_ln1 && d.temporal_frames > 0) {  // x += the NEXT block's temporal_embedding[frame of the row], here
+                f2.row_add = e->layers[li + 1].t_emb; f2.row_add_div = ntok; f2.row_add_mod = d.temporal_frames;
+            }
             if (mx_fc2) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
             else MERV_HIP(launch_gemm(f2, s));
             parts_valid = next_ln1;
@@ -668,6 +685,21 @@ extern "C" int merv_debug_gemm_stats(const void* A, const void* W, void* C, cons
     MERV_CHECK(act >= ACT_NONE && act <= ACT_QUICK_GELU, "merv_debug_gemm_stats: unknown activation");
     GemmArgs g = gemm_args((const bf16_t*)A, K, W, K, (bf16_t*)C, N, M, N, bias, act);
     g.lscale = lscale; g.res = (const bf16_t*)res; g.ldres = N; g.stats_out = stats_out;
+    MERV_HIP(launch_gemm(g, (hipStream_t)stream_));
+    return 0;
+}
+
+// test hook: the same with the row-indexed add of GemmArgs::row_add (table fp32 [row_add_mod, N]) behind the residual add
+extern "C" int merv_debug_gemm_row_add(const void* A, const void* W, void* C, const float* bias, const void* res, int32_t M, int32_t N,
+                                       int32_t K, const float* row_add, int32_t row_add_div, int32_t row_add_mod, float* stats_out,
+                                       void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(A && W && C && row_add && stats_out, "merv_debug_gemm_row_add: null argument");
+    MERV_CHECK(K > 0 && K % 64 == 0 && N > 0 && N % 128 == 0, "merv_debug_gemm_row_add: K % 64 == 0 and N % 128 == 0 required");
+    MERV_CHECK(row_add_div >= 256 && row_add_mod > 0, "merv_debug_gemm_row_add: row_add_div >= 256 and row_add_mod > 0 required");
+    GemmArgs g = gemm_args((const bf16_t*)A, K, W, K, (bf16_t*)C, N, M, N, bias, ACT_NONE);
+    g.res = (const bf16_t*)res; g.ldres = N; g.stats_out = stats_out;
+    g.row_add = row_add; g.row_add_div = row_add_div; g.row_add_mod = row_add_mod;
     MERV_HIP(launch_gemm(g, (hipStream_t)stream_));
     return 0;
 }

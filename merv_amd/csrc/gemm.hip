@@ -284,6 +284,20 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
 #pragma unroll
             for (int it = 0; it < EP_IT; ++it) resv[it] = u32x4{0u, 0u, 0u, 0u};
         }
+        // row-indexed add (GemmArgs::row_add): the part's rows are consecutive and row_add_div >= their number, so they belong to at
+        // most two groups; both candidate rows of the table are loaded once (this lane's 8 columns) and selected per output row
+        float ra[2][8];
+        int ra_boundary = 0x7fffffff;
+        if (p.row_add) {  // uniform
+            const int mb = __builtin_amdgcn_readfirstlane(m0 + wr * WTM_FULL + part * WTM) + p.row_add_row0;
+            const int f0 = mb / p.row_add_div, i0 = f0 % p.row_add_mod, i1 = i0 + 1 == p.row_add_mod ? 0 : i0 + 1;
+            ra_boundary = (f0 + 1) * p.row_add_div - p.row_add_row0;  // in this launch's row numbering
+            const float* t0 = p.row_add + (size_t)i0 * p.N + wn0 + ec * 8;
+            const float* t1 = p.row_add + (size_t)i1 * p.N + wn0 + ec * 8;
+            const float4 a0 = *(const float4*)t0, a1 = *(const float4*)(t0 + 4), b0 = *(const float4*)t1, b1 = *(const float4*)(t1 + 4);
+            ra[0][0] = a0.x; ra[0][1] = a0.y; ra[0][2] = a0.z; ra[0][3] = a0.w; ra[0][4] = a1.x; ra[0][5] = a1.y; ra[0][6] = a1.z; ra[0][7] = a1.w;
+            ra[1][0] = b0.x; ra[1][1] = b0.y; ra[1][2] = b0.z; ra[1][3] = b0.w; ra[1][4] = b1.x; ra[1][5] = b1.y; ra[1][6] = b1.z; ra[1][7] = b1.w;
+        }
         // part 0: every wave is done with the stage ring; later parts: this wave's reads of its staging region returned
         if (part == 0) MERV_GSTAMP(5);  // epilogue operands and part 0's residual rows requested
         if (part == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -320,6 +334,12 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
+            }
+            if (p.row_add) {  // uniform: bf16(x + table row), x already rounded by the residual add
+                const bool second = m0 + wr * WTM_FULL + part * WTM + r >= ra_boundary;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    t[q] = pack2bf(bflo(t[q]) + (second ? ra[1][2 * q] : ra[0][2 * q]), bfhi(t[q]) + (second ? ra[1][2 * q + 1] : ra[0][2 * q + 1]));
             }
             if (p.stats_out) {  // uniform: {sum, M2} of this row's 64 columns (the 8 lanes ec = 0..7 hold 8 values each)
                 float f[8];
@@ -1233,6 +1253,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 8 != 0) return hipErrorInvalidValue;
+    if (a.row_add && (a.act != ACT_NONE || a.row_add_div < 256 || a.row_add_mod <= 0 || a.out_group > 0 || a.mx_out_q)) return hipErrorInvalidValue;
     {   // the epilogue keeps element offsets in 32 bits
         const double rows_out = a.out_group > 0 ? ((double)(a.M / a.out_group) + 1) * a.out_stride + a.out_off : (double)a.M;
         if (rows_out * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
@@ -1262,6 +1283,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     rest.C = a.C + (size_t)rows1 * a.ldc;
     if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
     if (a.row_stats) rest.row_stats = a.row_stats + 2 * (size_t)rows1;
+    rest.row_add_row0 = a.row_add_row0 + rows1;
     if (a.stats_out) rest.stats_out = a.stats_out + 2 * (size_t)rows1;  // same stats_ld: the rows below the first launch's
     if (a.mx_out_q) {  // rows1 is a multiple of 256: whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
         rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;

@@ -37,6 +37,13 @@ struct GemmArgs {
     // kernel re-reads the residual stream for LayerNorm.
     float* stats_out;
     int stats_ld;             // rows of the partials array (0: M of this launch)
+    // a second, row-indexed additive term AFTER the residual add: C[m] = bf16(bf16(lin + res) + row_add[(m / row_add_div) % row_add_mod])
+    // (fp32 [row_add_mod, N]) -- LanguageBind's next block starts with x += temporal_embedding[frame]; its fc2 does that add, so
+    // the temporal LayerNorm can be folded like the others (statistics from stats_out, which sees the final values). Launches
+    // without an activation only; row_add_div >= 256 (a tile part then meets at most one boundary).
+    const float* row_add;
+    int row_add_div, row_add_mod;
+    int row_add_row0;         // row of the caller's problem that this launch's row 0 is (launch_gemm's second launch starts at rows1)
     // any launch: when mx_out_q is set the epilogue writes its (bf16-rounded) result as MXFP8 -- e4m3 [M, N] + block
     // scales in the layout of mx_quantize -- instead of bf16 C (the next GEMM's quantised input, e.g. fc1 -> fc2)
     uint8_t* mx_out_q;

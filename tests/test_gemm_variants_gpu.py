@@ -91,6 +91,40 @@ def test_epilogue_layernorm_partials(dev, M, N, K, act):
     assert torch.allclose(m2 / N, o.var(1, unbiased=False), rtol=1e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("M,N,K,div,mod", [(2056, 1024, 256, 257, 8), (33000, 1024, 4096, 257, 8), (700, 256, 1024, 300, 3), (257 * 9 + 5, 1024, 1024, 257, 8)])
+def test_epilogue_row_add(dev, M, N, K, div, mod):
+    """GemmArgs::row_add (LanguageBind: fc2 adds the NEXT block's temporal embedding[frame of the row] behind its residual add, so the
+    temporal LayerNorm folds into the temporal qkv GEMM): C = bf16(bf16(lin + res) + table[(m / div) % mod]) bit for bit against the
+    two bf16 steps in torch, for every tile configuration the launcher picks (eight-phase part + remaining rows at 33000), and the
+    LayerNorm partials describe the FINAL values."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    x = (torch.randn(M, N, generator=g) + 0.3).to(torch.bfloat16).to(dev)
+    table = torch.randn(mod, N, generator=g).to(dev)
+    parts = torch.full((N // 64, M, 2), float("nan"), device=dev)
+    out = x.clone()
+    check(lib.merv_debug_gemm_row_add(ptr(a), ptr(w), ptr(out), ptr(bias), ptr(out), M, N, K, ptr(table), div, mod, ptr(parts),
+                                      torch.cuda.current_stream(dev).cuda_stream), "merv_debug_gemm_row_add")
+    plain = x.clone()  # the same launch without the table: its output is bf16(lin + res)
+    parts0 = torch.empty_like(parts)
+    check(lib.merv_debug_gemm_stats(ptr(a), ptr(w), ptr(plain), ptr(bias), None, ptr(plain), M, N, K, 0, ptr(parts0),
+                                    torch.cuda.current_stream(dev).cuda_stream), "merv_debug_gemm_stats")
+    idx = (torch.arange(M, device=dev) // div) % mod
+    ref = (plain.float() + table[idx]).to(torch.bfloat16)
+    assert torch.equal(out, ref)
+    o = out.float()
+    parts = parts.transpose(0, 1)
+    mean = parts[..., 0].sum(1) / N
+    m2 = (parts[..., 1] + 64 * (parts[..., 0] / 64 - mean[:, None]) ** 2).sum(1)
+    assert torch.allclose(mean, o.mean(1), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(m2 / N, o.var(1, unbiased=False), rtol=1e-3, atol=1e-6)
+
+
 @pytest.mark.parametrize("variant", [7, 9])
 def test_erf_gelu_epilogue_polynomial_against_exact_gelu(dev, variant):
     """The erf-GELU of the GEMM epilogue is a clamped degree-8 minimax polynomial of Phi (common.h activate2): push EVERY finite
