@@ -51,10 +51,10 @@ KERNEL_CLASSES = [
     (8, "attention, K/V resident", "mfma", "attn_kernel<true,4,2,true,true>: LanguageBind 257 / DINOv2 261 tokens"),
     (9, "attention, K/V streamed", "mfma", "attn_kernel<true,4,2,false,false>: ViViT 3137 tokens; SigLIP 196 tokens"),
     (2, "temporal attention", "hbm", "temporal_attn_kernel (LanguageBind, t = 8)"),
-    (3, "LayerNorm", "hbm", "layernorm_kernel (pre_ln, temporal LN, ViViT final LN; the block LNs are folded into GEMMs)"),
+    (3, "LayerNorm", "hbm", "layernorm_kernel (pre_ln, LanguageBind block 0's temporal LN, ViViT final LN; every other LayerNorm is folded into a GEMM)"),
     (10, "LayerNorm statistics", "hbm", "row_stats_kernel + stats_finalize_kernel"),
     (11, "pool + fusion", "hbm", "pool_kernel, fusion_score_kernel + fusion_mix_kernel"),
-    (12, "data movement", "hbm", "im2col_kernel, prefix_kernel"),
+    (12, "data movement", "hbm", "im2col_fast_kernel, prefix_kernel, gather_tokens_kernel"),
 ]
 
 

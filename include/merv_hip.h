@@ -318,9 +318,10 @@ int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flo
 
 /*
  * Batch-1 token decode of the LLM hand-off: the per-token forward HF GenerationMixin runs for
- * the reference's generate() (merv/models/vidlms/merv.py:818-825 -> LlamaForCausalLM.forward with a KV cache). The prefill
- * stays on PyTorch-ROCm (north_star); a decode step is 5 launches per layer of these HBM-bound kernels instead of ~35
- * PyTorch ones. bf16 tensors, fp32 accumulation, bf16 rounding wherever the module materialises a bf16 tensor.
+ * the reference's generate() (merv/models/vidlms/merv.py:818-825 -> LlamaForCausalLM.forward with a KV cache). A decode step is
+ * 5 launches per layer of these HBM-bound kernels instead of ~35 PyTorch ones; the prompt prefill keeps its GEMMs on the library
+ * (PyTorch-ROCm) and takes the merv_prefill_* / merv_add_rmsnorm / merv_silu_mul calls below for everything between them.
+ * bf16 tensors, fp32 accumulation, bf16 rounding wherever the module materialises a bf16 tensor.
  *  merv_decode_rmsnorm     LlamaRMSNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)); x, y [rows, D], w [D]
  *  merv_decode_gemv        nn.Linear at M = 1: y[N] = bf16(W[N,K] x[K]) (+ res[N]); with W2: y = silu(bf16(W x)) * bf16(W2 x)
  *                          (LlamaMLP's act_fn(gate_proj(x)) * up_proj(x)); y32 != NULL: fp32 output instead (logits);

@@ -302,6 +302,50 @@ def test_prefill_rope_cache_rows(dev):
     assert torch.equal(Kc[:, keep], K0[:, keep]) and torch.equal(Vc[:, keep], V0[:, keep])
 
 
+def test_fused_attention_handoff_stress(dev):
+    """The in-launch hand-off of merv_decode_attention_fused (split partials -> write-through stores -> vmcnt(0) -> ticket -> the last
+    block merges) under timing noise: 400 launches at random positions, two back to back on the same workspace each time, with a second
+    stream hammering HBM every third iteration -- every one bit-equal to the three-kernel sequence, counters back at zero. (The
+    3000-iteration form is tools/probes/decode_attention_stress.py.)"""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    H, Hkv, hd, max_len, ns = 32, 8, 128, 2048, 8
+    g = torch.Generator().manual_seed(1)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    Kc, Vc = bf(torch.randn(Hkv, max_len, hd, generator=g)), bf(torch.randn(Hkv, max_len, hd, generator=g))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    emb = torch.outer(torch.arange(max_len, dtype=torch.float32), inv)
+    emb = torch.cat([emb, emb], -1)
+    cos, sin = bf(emb.cos()), bf(emb.sin())
+    ws = torch.zeros(lib.merv_decode_attention_fused_workspace_floats(H, ns), dtype=torch.float32, device=dev)
+    ws_a = torch.empty(lib.merv_decode_attention_workspace_floats(H, ns), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream(dev)
+    big = torch.randn(32, 1024, 1024, device=dev)
+    st = _st(dev)
+    bad = 0
+    for it in range(400):
+        pos = int(torch.randint(0, max_len - 1, (1,), generator=g))
+        q, k, v = bf(torch.randn(H * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g))
+        p = torch.tensor([pos], dtype=torch.int64, device=dev)
+        Ka, Va, q2 = Kc.clone(), Vc.clone(), torch.empty_like(q)
+        out_a = torch.empty(H * hd, dtype=torch.bfloat16, device=dev)
+        check(lib.merv_decode_rope_cache(ptr(q), ptr(k), ptr(v), ptr(q2), ptr(Ka), ptr(Va), ptr(cos), ptr(sin), ptr(p), H, Hkv, hd, max_len, st), "rope")
+        check(lib.merv_decode_attention(ptr(q2), ptr(Ka), ptr(Va), ptr(out_a), ptr(ws_a), ptr(p), H, Hkv, hd, max_len, ns, hd**-0.5, st), "attn")
+        Kb, Vb = Kc.clone(), Vc.clone()
+        out_b = torch.full((H * hd,), float("nan"), dtype=torch.bfloat16, device=dev)
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                big.mul_(1.0001)
+        for _ in range(2):
+            check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(out_b), ptr(ws),
+                                                  H, Hkv, hd, max_len, ns, hd**-0.5, st), "fused")
+        bad += int(not (torch.equal(out_a, out_b) and torch.equal(Ka, Kb) and torch.equal(Va, Vb)))
+    torch.cuda.synchronize(dev)
+    assert bad == 0
+    assert int(ws[H * ns * 130:].view(torch.int32).abs().sum()) == 0  # every head's arrival counter restored
+
+
 @pytest.mark.parametrize("S,H,Hkv", [(1, 2, 2), (37, 4, 2), (128, 2, 1), (129, 2, 2), (449, 4, 4), (1049, 8, 2)])
 def test_prefill_attention_vs_sdpa(dev, S, H, Hkv):
     """merv_prefill_attention (causal, head dim 128, K / V read from the cache layout, output in the o-projection's layout) against

@@ -23,7 +23,7 @@ RULES = [
     (r"layernorm_kernel", "LayerNorm"),
     (r"row_stats_kernel|stats_finalize_kernel", "LayerNorm statistics"),
     (r"pool_kernel|fusion_score_kernel|fusion_mix_kernel", "pool + fusion"),
-    (r"im2col_kernel|prefix_kernel|gather_tokens_kernel", "data movement"),
+    (r"im2col_kernel|im2col_fast_kernel|prefix_kernel|gather_tokens_kernel", "data movement"),
 ]
 
 
