@@ -378,6 +378,16 @@ size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
+/* The same two steps with the merge moved into the o-projection (round 4; bit-identical to merv_decode_attention_fused followed by
+ * merv_decode_gemv(Wo, NULL, out, x, x, ...)): merv_decode_attention_split ends at the split partials (ws: the first
+ * H * nsplit * (hd + 2) floats of the fused call's workspace; no counters, no `out`), merv_decode_oproj_merge computes
+ * y[N] = res[N] + Wo[N, H*hd] . merge(ws), merging while its first weight loads are in flight, and optionally stores the merged
+ * attention output [H*hd] (attn_out, NULL to skip). 9.0 + 9.3 us per layer against 13.8 + 9.3 at 1050 positions. */
+int merv_decode_attention_split(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
+                                void *k_cache, void *v_cache, float *ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
+                                int32_t nsplit, float scale, void *stream);
+int merv_decode_oproj_merge(const void *Wo, const void *res, void *y, const float *ws, void *attn_out, int32_t N, int32_t H, int32_t hd,
+                            int32_t nsplit, void *stream);
 /* merv_decode_attention_fused and the o-projection with its residual, x[D] += Wo[D, H*hd] . attention, as ONE launch (bit-identical
  * to the two calls): one workgroup per (head, position range) whose second half -- four loader waves -- brings its 16 rows of Wo into
  * LDS while the first half runs the attention, so the o-projection's weight stream hides under the attention's latency chain. `out`

@@ -946,6 +946,30 @@ extern "C" int merv_decode_attention_fused(const void* q, const void* k, const v
     return 0;
 }
 
+extern "C" int merv_decode_attention_split(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t,
+                                           const int64_t* pos, void* k_cache, void* v_cache, float* ws, int32_t H, int32_t Hkv,
+                                           int32_t hd, int32_t max_len, int32_t nsplit, float scale, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && cos_t && sin_t && pos && k_cache && v_cache && ws, "merv_decode_attention_split: null argument");
+    MERV_CHECK(hd == 128, "merv_decode_attention_split: head_dim must be 128");
+    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attention_split: bad geometry");
+    DecodeAttnFusedArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
+                          (bf16_t*)v_cache, nullptr, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale};
+    MERV_HIP(launch_decode_attention_split(a, (hipStream_t)stream_));
+    return 0;
+}
+
+extern "C" int merv_decode_oproj_merge(const void* Wo, const void* res, void* y, const float* ws, void* attn_out, int32_t N, int32_t H,
+                                       int32_t hd, int32_t nsplit, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(Wo && y && ws, "merv_decode_oproj_merge: null argument");
+    MERV_CHECK(hd == 128 && H > 0 && H <= 256 && N > 0 && nsplit > 0 && nsplit <= 64, "merv_decode_oproj_merge: bad geometry (hd == 128, H <= 256)");
+    MERV_CHECK(((uintptr_t)Wo & 15) == 0 && ((uintptr_t)ws & 7) == 0, "merv_decode_oproj_merge: alignment");
+    DecodeOprojMergeArgs a{(const bf16_t*)Wo, (const bf16_t*)res, (bf16_t*)y, ws, (bf16_t*)attn_out, N, H, nsplit};
+    MERV_HIP(launch_decode_oproj_merge(a, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" size_t merv_decode_attn_oproj_counter_bytes(void) { return decode_attn_oproj_counter_bytes(); }
 
 extern "C" int merv_decode_attn_oproj(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t, const int64_t* pos,

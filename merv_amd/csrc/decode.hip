@@ -615,7 +615,10 @@ struct AttnLds {
 // h: head, s: position range. Chained: q / k / v are the q / k / v operation's outputs (sc1 loads behind the wait), the merged
 // head goes out as 4-byte write-through stores and EVERY block adds to the operation's counter when it is done -- the merging
 // block of a head after its output stores, so H * nsplit arrivals mean every head is merged.
-template <class HO>
+// SPLIT_ONLY (round 4, stand-alone launch): the launch ends at the partials -- written with plain stores, visible at the kernel
+// boundary -- and the o-projection launch merges them while its first weight trip is in flight (oproj_merge_kernel): no write-through,
+// no vmcnt(0) + barrier + ticket round trip, no second pass over the partials inside this launch's dependency chain (9.0 against 13.8 us).
+template <class HO, bool SPLIT_ONLY = false>
 MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, const int s, AttnLds& lds, const HO& ho) {
     const int grp_heads = p.H / p.Hkv;
     const int hkv = h / grp_heads;
@@ -688,12 +691,18 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
         // relaxed atomics write through / read past the non-coherent cache levels, which costs nothing beside an ordinary
         // store here, whereas a device-scope FENCE writes back and invalidates the whole L2 (measured: +15 us per layer)
         float* ws = ws_h + (size_t)s * (128 + 2);
-        __hip_atomic_store(ws + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == 0) {
-            __hip_atomic_store(ws + 128, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ws + 129, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SPLIT_ONLY) {
+            ws[d] = O;
+            if (d == 0) { ws[128] = M; ws[129] = L; }
+        } else {
+            __hip_atomic_store(ws + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(ws + 128, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ws + 129, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
+    if constexpr (SPLIT_ONLY) return;
     // publish (every store of this block acknowledged), then take a ticket; the last arrival of this head merges.
     // This is the write-through form of the in-launch hand-off (cdna_hip_programming.md Guideline 16, R1 in its counter form, and
     // MI355X_MICROARCH.md "Valid forms", first table row): every partial is stored sc1 (relaxed agent-scope atomic stores ARE
@@ -745,6 +754,128 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAttnFusedArgs p) {
     __shared__ AttnLds lds;
     attn_fused_body(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
+}
+__global__ __launch_bounds__(DA_THREADS) void decode_attn_split_kernel(DecodeAttnFusedArgs p) {
+    __shared__ AttnLds lds;
+    attn_fused_body<NoHandoff, true>(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
+}
+
+// ---- o-projection that merges the attention's split partials on the way in: y = res + W_o . merge(ws) ----
+// One workgroup of 8 waves per 16 output rows (256 workgroups at D = 4096: one per CU, two rows per wave). Every lane first requests
+// its whole first weight trip (ROWS x 8 chunks of 16 B), then the workgroup merges the H x nsplit partials once -- thread t the 8
+// values 8 t .. 8 t + 7 of the attention output, with the arithmetic of attn_fused_body's merging block, rounded to bf16 -- into LDS
+// (the requests are younger than the weight loads, so the merge runs while the weights are in flight), and after one barrier the
+// GEMV reads x from LDS. Per row the products are accumulated in the order of gemv_body<1, 8, false, 1> (the plain o-projection's
+// configuration): the result is bit-identical to merv_decode_attention_fused + merv_decode_gemv. Workgroup 0 also stores the
+// merged vector (the separate path's attention output).
+constexpr int OM_WAVES = 8, OM_ROWS = 2, OM_UN = 8;
+__global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojMergeArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char om_smem[];
+    bf16_t* x_lds = (bf16_t*)om_smem;  // [K]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = (blockIdx.x * OM_WAVES + wave) * OM_ROWS;
+    const int K = p.H * 128, nchunk = K >> 3;
+    const bf16_t* wrow[OM_ROWS];
+#pragma unroll
+    for (int r = 0; r < OM_ROWS; ++r) wrow[r] = p.W + (size_t)(n0 + r < p.N ? n0 + r : p.N - 1) * K;
+    u32x4 wv[OM_ROWS][OM_UN];
+    auto issue_w = [&](int c) {
+        c = c < nchunk ? c : 0;
+#pragma unroll
+        for (int u = 0; u < OM_UN; ++u) {
+            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+#pragma unroll
+            for (int r = 0; r < OM_ROWS; ++r) wv[r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[r] + cu * 8));
+        }
+    };
+    int c = lane;
+    issue_w(c);
+    // merge: 8 consecutive values per thread, all of head (8 t) / 128
+    for (int t = threadIdx.x; t < nchunk; t += OM_WAVES * 64) {
+        const int h = t >> 4, d0 = (t & 15) * 8;
+        const float* ws_h = p.ws + (size_t)h * p.nsplit * 130;
+        float L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.nsplit == 8) {  // the decoder's geometry: every partial requested before the first use (one round trip)
+            float2 ml[8], o2[8][4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                ml[q] = *(const float2*)(ws_h + q * 130 + 128);
+                const float2* op = (const float2*)(ws_h + q * 130 + d0);  // (130 floats per split: 8-byte alignment only)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o2[q][j] = op[j];
+            }
+            float M = -INFINITY;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) M = fmaxf(M, ml[q].x);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float w = ml[q].x == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml[q].x - M);
+                L = fmaf(w, ml[q].y, L);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    O[2 * j] = fmaf(w, o2[q][j].x, O[2 * j]);
+                    O[2 * j + 1] = fmaf(w, o2[q][j].y, O[2 * j + 1]);
+                }
+            }
+        } else {
+            float M = -INFINITY;
+            for (int q = 0; q < p.nsplit; ++q) M = fmaxf(M, ws_h[q * 130 + 128]);
+            for (int q = 0; q < p.nsplit; ++q) {
+                const float2 ml = *(const float2*)(ws_h + q * 130 + 128);
+                const float w = ml.x == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml.x - M);
+                L = fmaf(w, ml.y, L);
+                const float2* op = (const float2*)(ws_h + q * 130 + d0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 o2 = op[j];
+                    O[2 * j] = fmaf(w, o2.x, O[2 * j]);
+                    O[2 * j + 1] = fmaf(w, o2.y, O[2 * j + 1]);
+                }
+            }
+        }
+        u32x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = pack2bf(O[2 * j] / L, O[2 * j + 1] / L);
+        *(u32x4*)(x_lds + t * 8) = pk;
+        if (blockIdx.x == 0 && p.attn_out) *(u32x4*)(p.attn_out + t * 8) = pk;
+    }
+    __syncthreads();
+    float acc[OM_ROWS];
+#pragma unroll
+    for (int r = 0; r < OM_ROWS; ++r) acc[r] = 0.f;
+    for (; c < nchunk; c += 64 * OM_UN) {
+#pragma unroll
+        for (int u = 0; u < OM_UN; ++u) {
+            float xf[8];
+            const int cu = c + 64 * u;
+            unpack8f(*(const u32x4*)(x_lds + (cu < nchunk ? cu : 0) * 8), xf);
+            if (cu >= nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < OM_ROWS; ++r) {
+                float wf[8];
+                unpack8f(wv[r][u], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[r] = fmaf(wf[j], xf[j], acc[r]);
+            }
+        }
+        if (c + 64 * OM_UN < nchunk) issue_w(c + 64 * OM_UN);
+    }
+#pragma unroll
+    for (int r = 0; r < OM_ROWS; ++r) acc[r] = wave_sum64(acc[r]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < OM_ROWS; ++r) {
+            const int n = n0 + r;
+            if (n >= p.N) break;
+            float v = round_bf(acc[r]);                 // the nn.Linear output as a bf16 tensor
+            if (p.res) v = v + bf2f(p.res[n]);          // x + o_proj(...), rounded once more below
+            p.y[n] = f2bf(v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1018,6 +1149,18 @@ hipError_t launch_decode_attention(const DecodeAttnArgs& a, hipStream_t s) {
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s) {
+    if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attn_split_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s) {
+    if (a.H <= 0 || a.nsplit <= 0 || a.N <= 0 || a.H * 256 > 64 * 1024) return hipErrorInvalidValue;  // x image in LDS: 256 B per head
+    const int rows_per_block = OM_WAVES * OM_ROWS;
+    hipLaunchKernelGGL(oproj_merge_kernel, dim3((a.N + rows_per_block - 1) / rows_per_block), dim3(OM_WAVES * 64), a.H * 256, s, a);
     return hipGetLastError();
 }
 

@@ -404,6 +404,17 @@ struct DecodeAttnFusedArgs {  // rotary(q, k at *pos) + cache[*pos] <- k, v + sp
     float scale;
 };
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s);
+// the same launch ending at the partials (a.out unused; no counters): ws [H][nsplit][hd + 2] is complete when the launch is
+hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s);
+struct DecodeOprojMergeArgs {  // y = res + W . merge(ws): the o-projection behind launch_decode_attention_split
+    const bf16_t* W;     // [N, H * 128]
+    const bf16_t* res;   // [N] or nullptr
+    bf16_t* y;           // [N]
+    const float* ws;     // [H][nsplit][130]
+    bf16_t* attn_out;    // [H * 128] merged attention output (optional)
+    int N, H, nsplit;
+};
+hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s);
 
 // merv_decode_attention_fused + the o-projection with its residual (x += W_o . attention) as ONE launch: the workgroups' loader
 // waves bring W_o into LDS while the attention runs (decode.hip, decode_attn_oproj_kernel). Requires D == 16 * H * nsplit.

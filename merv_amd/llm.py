@@ -392,6 +392,9 @@ class HipDecoder(StaticDecoder):
     use_chain = os.environ.get("MERV_DECODE_CHAIN", "0") == "1"
     # attention + o-projection as one launch: bit-identical, measured 2.4 us per layer SLOWER than the two launches -- opt-in too
     use_attn_oproj = os.environ.get("MERV_DECODE_ATTN_OPROJ", "0") == "1"
+    # the attention launch ends at its split partials and the o-projection merges them under its first weight trip (bit-identical to
+    # the fused attention launch + the plain o-projection; 4.8 us per layer faster): default; MERV_DECODE_SPLIT_MERGE=0 restores them
+    use_split_merge = os.environ.get("MERV_DECODE_SPLIT_MERGE", "1") != "0"
 
     @staticmethod
     def chain_supported(hf_model) -> bool:
@@ -584,6 +587,13 @@ class HipDecoder(StaticDecoder):
                                                      ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5,
                                                      ptr(a.o_proj.weight), x, D, ptr(self.ao_counters) + 4 * li * self.ao_stride,
                                                      ptr(self.chain_err), st), "merv_decode_attn_oproj")
+                elif self.use_split_merge and H <= 256:
+                    # rotary + cache + split attention; then x += o_proj(merge of the splits): the merge rides under the weight loads
+                    check(lib.merv_decode_attention_split(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
+                                                          ptr(self.V[li]), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5, st),
+                          "merv_decode_attention_split")
+                    check(lib.merv_decode_oproj_merge(ptr(a.o_proj.weight), x, x, ptr(self.ws), 0, D, H, hd, self.NSPLIT, st),
+                          "merv_decode_oproj_merge")
                 else:
                     check(lib.merv_decode_attention_fused(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
                                                           ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT,

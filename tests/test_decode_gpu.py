@@ -302,6 +302,41 @@ def test_prefill_rope_cache_rows(dev):
     assert torch.equal(Kc[:, keep], K0[:, keep]) and torch.equal(Vc[:, keep], V0[:, keep])
 
 
+@pytest.mark.parametrize("H,Hkv,pos,D", [(32, 32, 1049, 4096), (32, 8, 300, 4096), (8, 2, 5, 1000), (40, 40, 77, 5120), (4, 4, 0, 512)])
+def test_split_attention_and_merging_oproj_equal_the_fused_pair(dev, H, Hkv, pos, D):
+    """merv_decode_attention_split + merv_decode_oproj_merge == merv_decode_attention_fused + merv_decode_gemv(o_proj, residual), bit
+    for bit: same caches, same merged attention vector, same x -- and x may be updated in place."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    hd, max_len, ns = 128, 1280, 8
+    g = torch.Generator().manual_seed(H + pos)
+    bf = lambda t: t.to(torch.bfloat16).to(dev)
+    Kc, Vc = bf(torch.randn(Hkv, max_len, hd, generator=g)), bf(torch.randn(Hkv, max_len, hd, generator=g))
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    emb = torch.outer(torch.arange(max_len, dtype=torch.float32), inv)
+    emb = torch.cat([emb, emb], -1)
+    cos, sin = bf(emb.cos()), bf(emb.sin())
+    q, k, v = bf(torch.randn(H * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g))
+    Wo = bf(torch.randn(D, H * hd, generator=g) * (H * hd) ** -0.5)
+    x0 = bf(torch.randn(D, generator=g))
+    p = torch.tensor([pos], dtype=torch.int64, device=dev)
+    st = _st(dev)
+    ws = torch.zeros(lib.merv_decode_attention_fused_workspace_floats(H, ns), dtype=torch.float32, device=dev)
+    Ka, Va, out_a, xa = Kc.clone(), Vc.clone(), torch.empty(H * hd, dtype=torch.bfloat16, device=dev), x0.clone()
+    check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Ka), ptr(Va), ptr(out_a), ptr(ws), H, Hkv, hd,
+                                          max_len, ns, hd**-0.5, st), "fused")
+    check(lib.merv_decode_gemv(ptr(Wo), 0, ptr(out_a), ptr(xa), ptr(xa), 0, D, H * hd, 0, 0.0, st), "o_proj")
+    ws2 = torch.full((H * ns * 130,), float("nan"), dtype=torch.float32, device=dev)
+    Kb, Vb, out_b, xb = Kc.clone(), Vc.clone(), torch.empty(H * hd, dtype=torch.bfloat16, device=dev), x0.clone()
+    check(lib.merv_decode_attention_split(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(ws2), H, Hkv, hd, max_len,
+                                          ns, hd**-0.5, st), "split")
+    check(lib.merv_decode_oproj_merge(ptr(Wo), ptr(xb), ptr(xb), ptr(ws2), ptr(out_b), D, H, hd, ns, st), "oproj_merge")
+    assert torch.equal(Ka, Kb) and torch.equal(Va, Vb)
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(xa, xb)
+
+
 def test_fused_attention_handoff_stress(dev):
     """The in-launch hand-off of merv_decode_attention_fused (split partials -> write-through stores -> vmcnt(0) -> ticket -> the last
     block merges) under timing noise: 400 launches at random positions, two back to back on the same workspace each time, with a second

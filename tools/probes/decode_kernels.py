@@ -65,6 +65,11 @@ def main():
             ptr(d.q), ptr(d.k), ptr(d.v), ptr(d.cos), ptr(d.sin), pos, ptr(d.K[li]), ptr(d.V[li]), ptr(d.ao), ptr(d.ws), H, Hkv, hd, d.max_len,
             d.NSPLIT, hd**-0.5, st), "attn"),
         "o_proj + residual": lambda l, li, st: gemv(l.self_attn.o_proj.weight, None, ptr(d.ao), x, ptr(scratch), D, H * hd, st),
+        "rotary + cache + split attention (no merge)": lambda l, li, st: check(lib.merv_decode_attention_split(
+            ptr(d.q), ptr(d.k), ptr(d.v), ptr(d.cos), ptr(d.sin), pos, ptr(d.K[li]), ptr(d.V[li]), ptr(d.ws), H, Hkv, hd, d.max_len,
+            d.NSPLIT, hd**-0.5, st), "split"),
+        "o_proj merging the splits + residual": lambda l, li, st: check(lib.merv_decode_oproj_merge(
+            ptr(l.self_attn.o_proj.weight), x, ptr(scratch), ptr(d.ws), 0, D, H, hd, d.NSPLIT, st), "om"),
         "attention + o_proj, one launch": lambda l, li, st: check(lib.merv_decode_attn_oproj(
             ptr(d.q), ptr(d.k), ptr(d.v), ptr(d.cos), ptr(d.sin), pos, ptr(d.K[li]), ptr(d.V[li]), ptr(d.ao), ptr(d.ws), H, Hkv, hd, d.max_len,
             d.NSPLIT, hd**-0.5, ptr(l.self_attn.o_proj.weight), ptr(scratch), D, ptr(d.ao_counters) + 4 * li * d.ao_stride, ptr(d.chain_err), st), "ao"),
@@ -74,11 +79,13 @@ def main():
     }
     res = {}
     total = 0.0
+    if os.environ.get("DEC_SKIP_AO") == "1":
+        classes.pop("attention + o_proj, one launch")
     for name, fn in classes.items():
         g = graph_of(fn)
         t = timeit(g.replay) / len(m.model.layers)
         res[name] = round(t * 1e6, 2)
-        if "one launch" not in name:
+        if "one launch" not in name and "split" not in name:
             total += t
     res["sum_per_layer_us"] = round(total * 1e6, 2)
     res["step_graph_ms"] = round(timeit(lambda: d.decode(tok)) * 1e3, 3)
