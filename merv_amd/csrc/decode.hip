@@ -1109,6 +1109,16 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
         const int r = cfg[0] - '0', u = cfg[1] - '0';
         if ((r == 2 && u == 4) || (r == 1 && (u == 4 || u == 8) && !a.norm_w)) { rows = r; un = u; }
     }
+    if (rows == 1 && un == 8 && !(cfg && cfg[0])) {
+        // a trip is 64 lanes x UN chunks and the last one is padded with clamped (wasted) loads: K = 11008 is 1376 chunks = 3 trips
+        // of 512 with 160 wasted, or 2 trips of 704 (UN = 11) with 32 -- same per-lane chunk order, so the same bits
+        const int nchunk = a.K >> 3;
+        const int waste8 = (nchunk + 511) / 512 * 512 - nchunk, waste11 = (nchunk + 703) / 704 * 704 - nchunk;
+        if (waste11 + 64 < waste8) {
+            hipLaunchKernelGGL((gemv_kernel<1, 11, false, 1>), dim3((a.N + GEMV_WAVES - 1) / GEMV_WAVES), dim3(GEMV_WAVES * 64), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (rows == 1 && un == 8) return launch_gemv_cfg<1, 8>(a, s);
     if (rows == 1) return launch_gemv_cfg<1, 4>(a, s);
     return launch_gemv_cfg<2, 4>(a, s);
