@@ -379,10 +379,12 @@ int merv_decode_attention_fused(const void *q, const void *k, const void *v, con
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
 /* The same two steps with the merge moved into the o-projection (round 4; bit-identical to merv_decode_attention_fused followed by
- * merv_decode_gemv(Wo, NULL, out, x, x, ...)): merv_decode_attention_split ends at the split partials (ws: the first
- * H * nsplit * (hd + 2) floats of the fused call's workspace; no counters, no `out`), merv_decode_oproj_merge computes
+ * merv_decode_gemv(Wo, NULL, out, x, x, ...)): merv_decode_attention_split ends at the split partials (ws:
+ * merv_decode_attention_split_workspace_floats(H, nsplit) floats, 16-byte aligned, records of 132; no counters, no `out`, nothing to
+ * zero), merv_decode_oproj_merge computes
  * y[N] = res[N] + Wo[N, H*hd] . merge(ws), merging while its first weight loads are in flight, and optionally stores the merged
  * attention output [H*hd] (attn_out, NULL to skip). 9.0 + 9.3 us per layer against 13.8 + 9.3 at 1050 positions. */
+size_t merv_decode_attention_split_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_split(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, float *ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
                                 int32_t nsplit, float scale, void *stream);

@@ -120,6 +120,7 @@ SIGNATURES = {
     "merv_decode_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_attention_fused_workspace_floats": (_sz, [_i32, _i32]),
     "merv_decode_attention_fused": (C.c_int, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "merv_decode_attention_split_workspace_floats": (_sz, [_i32, _i32]),
     "merv_decode_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_oproj_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_decode_attn_oproj_counter_bytes": (_sz, []),

@@ -946,6 +946,11 @@ extern "C" int merv_decode_attention_fused(const void* q, const void* k, const v
     return 0;
 }
 
+extern "C" size_t merv_decode_attention_split_workspace_floats(int32_t H, int32_t nsplit) {
+    if (H <= 0 || nsplit <= 0) return 0;
+    return decode_attention_split_workspace_floats(H, nsplit);
+}
+
 extern "C" int merv_decode_attention_split(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t,
                                            const int64_t* pos, void* k_cache, void* v_cache, float* ws, int32_t H, int32_t Hkv,
                                            int32_t hd, int32_t max_len, int32_t nsplit, float scale, void* stream_) {
@@ -964,7 +969,7 @@ extern "C" int merv_decode_oproj_merge(const void* Wo, const void* res, void* y,
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(Wo && y && ws, "merv_decode_oproj_merge: null argument");
     MERV_CHECK(hd == 128 && H > 0 && H <= 256 && N > 0 && nsplit > 0 && nsplit <= 64, "merv_decode_oproj_merge: bad geometry (hd == 128, H <= 256)");
-    MERV_CHECK(((uintptr_t)Wo & 15) == 0 && ((uintptr_t)ws & 7) == 0, "merv_decode_oproj_merge: alignment");
+    MERV_CHECK(((uintptr_t)Wo & 15) == 0 && ((uintptr_t)ws & 15) == 0, "merv_decode_oproj_merge: 16-byte alignment required");
     DecodeOprojMergeArgs a{(const bf16_t*)Wo, (const bf16_t*)res, (bf16_t*)y, ws, (bf16_t*)attn_out, N, H, nsplit};
     MERV_HIP(launch_decode_oproj_merge(a, (hipStream_t)stream_));
     return 0;

@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(SiluMulArgs p) {
 // Each block takes positions [s * chunk, (s + 1) * chunk) of [0, pos]; every 16-lane group keeps a running (m, l, o[8]);
 // groups and waves are merged through LDS; the block writes (m, l, o[hd]) to the workspace.
 constexpr int DA_THREADS = 256;
+constexpr int DA_SPLIT_STRIDE = 132;  // floats per (head, range) partial of the split-only attention launch: [o 128][m][l][2 pad]
 constexpr int DA_UN = 4;  // cache positions per 16-lane group per trip: 2 x DA_UN 16-byte loads in flight per lane (8 / 12: 14.0 / 13.6 us against 14.0)
 
 struct DaState {  // running (max, sum, out[8 dims of this lane]) of one 16-lane group
@@ -674,7 +675,10 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
 #pragma unroll
     for (int i = 0; i < 8; ++i) lds.o[g][sub * 8 + i] = st.o[i];
     __syncthreads();
-    float* ws_h = p.ws + (size_t)h * p.nsplit * (128 + 2);
+    // partial layout: [o 128][m][l] per (head, range); the split-only launch pads the record to 132 floats so that the merging
+    // o-projection reads 16-byte aligned rows
+    constexpr int PS = SPLIT_ONLY ? DA_SPLIT_STRIDE : 130;
+    float* ws_h = p.ws + (size_t)h * p.nsplit * PS;
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
         float M = -INFINITY;
@@ -690,7 +694,7 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
         // the partials travel between blocks (possibly between XCDs, each with its own L2) inside one launch: device-scope
         // relaxed atomics write through / read past the non-coherent cache levels, which costs nothing beside an ordinary
         // store here, whereas a device-scope FENCE writes back and invalidates the whole L2 (measured: +15 us per layer)
-        float* ws = ws_h + (size_t)s * (128 + 2);
+        float* ws = ws_h + (size_t)s * PS;
         if constexpr (SPLIT_ONLY) {
             ws[d] = O;
             if (d == 0) { ws[128] = M; ws[129] = L; }
@@ -794,16 +798,21 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
     // merge: 8 consecutive values per thread, all of head (8 t) / 128
     for (int t = threadIdx.x; t < nchunk; t += OM_WAVES * 64) {
         const int h = t >> 4, d0 = (t & 15) * 8;
-        const float* ws_h = p.ws + (size_t)h * p.nsplit * 130;
+        constexpr int PS = DA_SPLIT_STRIDE;
+        const float* ws_h = p.ws + (size_t)h * p.nsplit * PS;
         float L = 0.f, O[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto accumulate = [&](float w, const float4& a, const float4& b) {
+            O[0] = fmaf(w, a.x, O[0]); O[1] = fmaf(w, a.y, O[1]); O[2] = fmaf(w, a.z, O[2]); O[3] = fmaf(w, a.w, O[3]);
+            O[4] = fmaf(w, b.x, O[4]); O[5] = fmaf(w, b.y, O[5]); O[6] = fmaf(w, b.z, O[6]); O[7] = fmaf(w, b.w, O[7]);
+        };
         if (p.nsplit == 8) {  // the decoder's geometry: every partial requested before the first use (one round trip)
-            float2 ml[8], o2[8][4];
+            float2 ml[8];
+            float4 oa[8], ob[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                ml[q] = *(const float2*)(ws_h + q * 130 + 128);
-                const float2* op = (const float2*)(ws_h + q * 130 + d0);  // (130 floats per split: 8-byte alignment only)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o2[q][j] = op[j];
+                ml[q] = *(const float2*)(ws_h + q * PS + 128);
+                oa[q] = *(const float4*)(ws_h + q * PS + d0);
+                ob[q] = *(const float4*)(ws_h + q * PS + d0 + 4);
             }
             float M = -INFINITY;
 #pragma unroll
@@ -812,26 +821,16 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
             for (int q = 0; q < 8; ++q) {
                 const float w = ml[q].x == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml[q].x - M);
                 L = fmaf(w, ml[q].y, L);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    O[2 * j] = fmaf(w, o2[q][j].x, O[2 * j]);
-                    O[2 * j + 1] = fmaf(w, o2[q][j].y, O[2 * j + 1]);
-                }
+                accumulate(w, oa[q], ob[q]);
             }
         } else {
             float M = -INFINITY;
-            for (int q = 0; q < p.nsplit; ++q) M = fmaxf(M, ws_h[q * 130 + 128]);
+            for (int q = 0; q < p.nsplit; ++q) M = fmaxf(M, ws_h[q * PS + 128]);
             for (int q = 0; q < p.nsplit; ++q) {
-                const float2 ml = *(const float2*)(ws_h + q * 130 + 128);
+                const float2 ml = *(const float2*)(ws_h + q * PS + 128);
                 const float w = ml.x == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(ml.x - M);
                 L = fmaf(w, ml.y, L);
-                const float2* op = (const float2*)(ws_h + q * 130 + d0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float2 o2 = op[j];
-                    O[2 * j] = fmaf(w, o2.x, O[2 * j]);
-                    O[2 * j + 1] = fmaf(w, o2.y, O[2 * j + 1]);
-                }
+                accumulate(w, *(const float4*)(ws_h + q * PS + d0), *(const float4*)(ws_h + q * PS + d0 + 4));
             }
         }
         u32x4 pk;
@@ -1162,6 +1161,7 @@ hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream
     return hipGetLastError();
 }
 
+size_t decode_attention_split_workspace_floats(int H, int nsplit) { return (size_t)H * nsplit * DA_SPLIT_STRIDE; }
 hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attn_split_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);

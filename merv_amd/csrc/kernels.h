@@ -404,13 +404,15 @@ struct DecodeAttnFusedArgs {  // rotary(q, k at *pos) + cache[*pos] <- k, v + sp
     float scale;
 };
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s);
-// the same launch ending at the partials (a.out unused; no counters): ws [H][nsplit][hd + 2] is complete when the launch is
+// the same launch ending at the partials (a.out unused; no counters): ws [H][nsplit][132] = (o[128], m, l, 2 pad) is complete when
+// the launch is; decode_attention_split_workspace_floats(H, nsplit) floats, 16-byte aligned
 hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s);
+size_t decode_attention_split_workspace_floats(int H, int nsplit);
 struct DecodeOprojMergeArgs {  // y = res + W . merge(ws): the o-projection behind launch_decode_attention_split
     const bf16_t* W;     // [N, H * 128]
     const bf16_t* res;   // [N] or nullptr
     bf16_t* y;           // [N]
-    const float* ws;     // [H][nsplit][130]
+    const float* ws;     // [H][nsplit][132], the split launch's layout
     bf16_t* attn_out;    // [H * 128] merged attention output (optional)
     int N, H, nsplit;
 };

@@ -376,7 +376,8 @@ class HipDecoder(StaticDecoder):
         self.x, self.h, self.ao, self.mid = mk(D), mk(D), mk(self.H * self.hd), mk(I)
         self.q, self.k, self.v = mk(self.H * self.hd), mk(self.Hkv * self.hd), mk(self.Hkv * self.hd)
         # partials of the split attention + one arrival counter per head (zero between launches: the kernel restores them)
-        self.ws = torch.zeros(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT), dtype=torch.float32, device=self.dev)
+        self.ws = torch.zeros(max(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT),
+                                  self.lib.merv_decode_attention_split_workspace_floats(self.H, self.NSPLIT)), dtype=torch.float32, device=self.dev)
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
         self.chain = None  # built at the first step (the position tensor it points to is created by prefill())
         self._want_chain = self.use_chain and self.chain_supported(hf_model)

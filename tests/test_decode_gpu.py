@@ -327,7 +327,7 @@ def test_split_attention_and_merging_oproj_equal_the_fused_pair(dev, H, Hkv, pos
     check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Ka), ptr(Va), ptr(out_a), ptr(ws), H, Hkv, hd,
                                           max_len, ns, hd**-0.5, st), "fused")
     check(lib.merv_decode_gemv(ptr(Wo), 0, ptr(out_a), ptr(xa), ptr(xa), 0, D, H * hd, 0, 0.0, st), "o_proj")
-    ws2 = torch.full((H * ns * 130,), float("nan"), dtype=torch.float32, device=dev)
+    ws2 = torch.full((lib.merv_decode_attention_split_workspace_floats(H, ns),), float("nan"), dtype=torch.float32, device=dev)
     Kb, Vb, out_b, xb = Kc.clone(), Vc.clone(), torch.empty(H * hd, dtype=torch.bfloat16, device=dev), x0.clone()
     check(lib.merv_decode_attention_split(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(ws2), H, Hkv, hd, max_len,
                                           ns, hd**-0.5, st), "split")
