@@ -168,6 +168,35 @@ def test_attention_spiked_max(dev):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("L", [196, 257, 300, 3137])
+def test_attention_first_tile_reference(dev, L):
+    """Extreme first key tiles: queries whose scores against EVERY key are ~ -128 nats, ~ +128 nats, and one whose first tile is
+    ~ -128 while a later key is ~ +40 (the running reference has to start from the tile's own maximum and move far); each at the
+    shipped threshold, thr = 0 and thr = 64."""
+    from merv_amd import _lib, ops
+    lib = _lib.load()
+    heads, D = 2, 128
+    g = torch.Generator().manual_seed(L)
+    qkv = torch.randn(L, 3 * D, generator=g) * 0.3
+    qkv[:, D:D + 64] += 4.0                 # every key of head 0 points along +1 (norm ~ 4 * 8)
+    qkv[5, :64] = -4.0                      # query 5: scores ~ -4 * 4 * 64 / 8 = -128 nats against all keys
+    qkv[6, :64] = 4.0                       # query 6: ~ +128 nats against all keys
+    qkv[40, :64] = -4.0                     # query 40: ~ -128 everywhere ...
+    qkv[L - 3, D:D + 64] = -1.25            # ... except one late key: +40 nats
+    qkv = _bf(qkv).to(dev)
+    ref = _attn_ref(qkv, 1, L, heads)
+    try:
+        for thr in (8.0, 0.0, 64.0):
+            lib.merv_debug_set_attn_rescale_thr(thr)
+            out = ops.attention(qkv, 1, L, heads)
+            assert torch.isfinite(out.float()).all(), thr
+            assert rel_l2(out, ref) < 1e-2, (thr, L)
+            per_row = ((out.float().cpu() - ref.cpu()).norm(dim=-1) / (ref.cpu().norm(dim=-1) + 1e-20))
+            assert float(per_row.max()) < 3e-2, (thr, L, int(per_row.argmax()))
+    finally:
+        lib.merv_debug_set_attn_rescale_thr(8.0)
+
+
 @pytest.mark.parametrize("vtr", ["1", "0"])
 @pytest.mark.parametrize("L", [257, 258, 261, 264, 265])
 def test_attention_extra_rows_split_over_key_tiles(dev, vtr, L):
