@@ -1170,6 +1170,9 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     }
 }
 
+#ifdef MERV_ABL_REST
+__global__ void noop_kernel() {}
+#endif
 int g_gemm_variant = 0;
 int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
@@ -1277,6 +1280,13 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     top.M = rows1;
     hipError_t e = dispatch(top, true);
     if (e != hipSuccess || rows1 == a.M) return e;
+#ifdef MERV_ABL_REST  // ablation builds (wrong results): 1 = the remaining rows are not computed at all, 2 = an empty launch in their place
+    if (MERV_ABL_REST == 1) return e;
+    if (MERV_ABL_REST == 2) {
+        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s);
+        return hipGetLastError();
+    }
+#endif
     GemmArgs rest = a;  // independent rows: same stream, no ordering requirement between the two launches
     rest.M = a.M - rows1;
     rest.A = a.A + (size_t)rows1 * a.lda;
