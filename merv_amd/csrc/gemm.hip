@@ -1223,7 +1223,10 @@ int plan_split(const GemmArgs& a) {
     const long rounds = full_m * tilesN / num_cus();
     // less than one round (small batches): one partial round of the eight-phase kernel still beats two rounds of 256x128
     // tiles once it has enough blocks (measured end to end against never doing so: +12 % tokens/s at 1 video per step, +8 % at 2, +1 % at 4; threshold 32 vs 96: +5.8 % at 1)
-    if (rounds < 1) return (full_m * tilesN >= SUBROUND_MIN_TILES) ? a.M : 0;
+    if (rounds < 1) {
+        static const long min_tiles = getenv("MERV_SUBROUND_MIN_TILES") ? atol(getenv("MERV_SUBROUND_MIN_TILES")) : SUBROUND_MIN_TILES;  // tuning hook
+        return (full_m * tilesN >= min_tiles) ? a.M : 0;
+    }
     long k = rounds * num_cus() / tilesN;
     if (k > full_m) k = full_m;
     return (int)(k * 256);
