@@ -30,6 +30,22 @@ from .encoder import EncoderSpec, HipEncoder
 from .projector import CrossAttentionAdapterLearnableQuery
 
 
+# The encoder side streams are shared by every path object of a device. HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4)
+# hardware queues in creation order: the first four side streams of a process get one queue each, a second path's own four would be
+# folded onto fewer queues and its encoders partly serialised (measured at one video per call: 11.4 against 9.4 ms; with
+# GPU_MAX_HW_QUEUES=8 both 9.4; tools/probes/alloc_order_probe.py). Work on them is stream-ordered and event-joined per call, so
+# paths that share them stay correct even when driven from different threads.
+_ENCODER_STREAMS: Dict[int, List["torch.cuda.Stream"]] = {}
+
+
+def _encoder_streams(device: torch.device, n: int) -> List["torch.cuda.Stream"]:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _ENCODER_STREAMS.setdefault(idx, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:n]
+
+
 class MervVisualPath:
     def __init__(self, specs: Sequence[EncoderSpec], enc_weights: Optional[Sequence[Dict]],
                  proj_weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
@@ -58,7 +74,7 @@ class MervVisualPath:
             raise ValueError(f"Output token length is not consistent across projectors: {self.tokens_out}")
         self.T_vis = self.tokens_out.pop()
         self.concurrent = concurrent_streams and len(self.encoders) > 1
-        self.streams = [torch.cuda.Stream(self.device) for _ in self.encoders]
+        self.streams = _encoder_streams(self.device, len(self.encoders))
         self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
         self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
         self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
