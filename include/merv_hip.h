@@ -390,6 +390,11 @@ int merv_decode_attention_split(const void *q, const void *k, const void *v, con
                                 int32_t nsplit, float scale, void *stream);
 int merv_decode_oproj_merge(const void *Wo, const void *res, void *y, const float *ws, void *attn_out, int32_t N, int32_t H, int32_t hd,
                             int32_t nsplit, void *stream);
+/* Greedy decoding inside a captured step (HF GenerationMixin's greedy search: next token = argmax of the last logits,
+ * merv/models/vidlms/merv.py:818-825 with do_sample=False): tok[0] <- argmax(logits[V]) by torch.argmax's rule (the first maximum; a NaN
+ * wins), out_tokens[*pos - pos0] <- the token (out_tokens may be NULL), *pos += 1 -- so that a replayed step leaves the next step's
+ * token and position on the device and the host loop launches nothing else per token. */
+int merv_decode_greedy_advance(const float *logits, int32_t V, int64_t *tok, int64_t *pos, int64_t *out_tokens, int64_t pos0, void *stream);
 /* merv_decode_attention_fused and the o-projection with its residual, x[D] += Wo[D, H*hd] . attention, as ONE launch (bit-identical
  * to the two calls): one workgroup per (head, position range) whose second half -- four loader waves -- brings its 16 rows of Wo into
  * LDS while the first half runs the attention, so the o-projection's weight stream hides under the attention's latency chain. `out`

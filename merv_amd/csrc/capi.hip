@@ -975,6 +975,16 @@ extern "C" int merv_decode_oproj_merge(const void* Wo, const void* res, void* y,
     return 0;
 }
 
+extern "C" int merv_decode_greedy_advance(const float* logits, int32_t V, int64_t* tok, int64_t* pos, int64_t* out_tokens, int64_t pos0,
+                                          void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(logits && tok && pos, "merv_decode_greedy_advance: null argument");
+    MERV_CHECK(V > 0, "merv_decode_greedy_advance: V > 0 required");
+    static_assert(sizeof(long) == sizeof(int64_t), "int64 tokens");
+    MERV_HIP(launch_decode_greedy_advance(logits, V, (long*)tok, (long*)pos, (long*)out_tokens, (long)pos0, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" size_t merv_decode_attn_oproj_counter_bytes(void) { return decode_attn_oproj_counter_bytes(); }
 
 extern "C" int merv_decode_attn_oproj(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t, const int64_t* pos,

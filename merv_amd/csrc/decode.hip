@@ -764,6 +764,62 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_split_kernel(DecodeAtt
     attn_fused_body<NoHandoff, true>(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
 }
 
+// ---- greedy decoding inside the captured step: token = argmax(logits) (torch.argmax's rule: the first maximum; a NaN wins), ----
+// ---- tok[0] <- token, out_tokens[*pos - pos0] <- token, *pos += 1: what the host loop did with three PyTorch kernels per token ----
+__global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    bool nan = false;
+    auto take = [&](float v, int i) {  // ascending i per thread: a strict > keeps the first maximum
+        if (v != v) { if (!nan) { nan = true; idx = i; } }
+        else if (!nan && (v > best || idx == 0x7fffffff)) { best = v; idx = i; }
+    };
+    // 16 bytes per lane, eight loads in flight before the first compare (one block reads 128 KB of logits: latency, not bandwidth)
+    const int nvec = ((uintptr_t)logits & 15) == 0 ? V >> 2 : 0;
+    for (int b = threadIdx.x; b < nvec; b += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = b + u * 1024;
+            v[u] = c < nvec ? *(const float4*)(logits + 4 * c) : float4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = b + u * 1024;
+            if (c < nvec) { take(v[u].x, 4 * c); take(v[u].y, 4 * c + 1); take(v[u].z, 4 * c + 2); take(v[u].w, 4 * c + 3); }
+        }
+    }
+    for (int i = 4 * nvec + threadIdx.x; i < V; i += 1024) take(logits[i], i);
+    auto better = [](bool na, float va, int ia, bool nb, float vb, int ib) {  // is (b) ahead of (a)?
+        if (na != nb) return nb;
+        if (na) return ib < ia;
+        return vb > va || (vb == va && ib < ia);
+    };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        const bool on = __shfl_xor((int)nan, o, 64) != 0;
+        if (better(nan, best, idx, on, ov, oi)) { best = ov; idx = oi; nan = on; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[wave] = nan ? NAN : best; bi[wave] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = bv[0]; int ix = bi[0]; bool n = v != v;
+        for (int w = 1; w < 16; ++w) {
+            const bool wn = bv[w] != bv[w];
+            if (better(n, v, ix, wn, bv[w], bi[w])) { v = bv[w]; ix = bi[w]; n = wn; }
+        }
+        const long p = *pos;
+        tok[0] = ix;
+        if (out_tokens) out_tokens[p - pos0] = ix;
+        *pos = p + 1;
+    }
+}
+
 // ---- o-projection that merges the attention's split partials on the way in: y = res + W_o . merge(ws) ----
 // One workgroup of 8 waves per 16 output rows (256 workgroups at D = 4096: one per CU, two rows per wave). Every lane first requests
 // its whole first weight trip (ROWS x 8 chunks of 16 B), then the workgroup merges the H x nsplit partials once -- thread t the 8
@@ -1162,6 +1218,11 @@ hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream
 }
 
 size_t decode_attention_split_workspace_floats(int H, int nsplit) { return (size_t)H * nsplit * DA_SPLIT_STRIDE; }
+hipError_t launch_decode_greedy_advance(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s) {
+    if (V <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1024), 0, s, logits, V, tok, pos, out_tokens, pos0);
+    return hipGetLastError();
+}
 hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decode_attn_split_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);

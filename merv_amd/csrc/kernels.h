@@ -417,6 +417,8 @@ struct DecodeOprojMergeArgs {  // y = res + W . merge(ws): the o-projection behi
     int N, H, nsplit;
 };
 hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s);
+// greedy decoding inside a captured step: tok[0] <- argmax(logits[V]) (first maximum), out_tokens[*pos - pos0] <- it, *pos += 1
+hipError_t launch_decode_greedy_advance(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s);
 
 // merv_decode_attention_fused + the o-projection with its residual (x += W_o . attention) as ONE launch: the workgroups' loader
 // waves bring W_o into LDS while the attention runs (decode.hip, decode_attn_oproj_kernel). Requires D == 16 * H * nsplit.

@@ -183,6 +183,18 @@ class LlamaBackbone:
                 o = self.llm(input_ids=tok[:, None], past_key_values=state["past"], use_cache=True)
                 state["past"] = o.past_key_values
                 return o.logits[:, -1].float()
+        if (isinstance(dec, HipDecoder) and not do_sample and repetition_penalty == 1.0 and max_new_tokens > 0
+                and (eos_token_id is None or min_new_tokens == 0) and dec.use_greedy_graph):
+            # greedy search entirely on the device: every replayed step picks its own successor (HipDecoder.greedy_run)
+            first = logits.argmax(-1)
+            rest = dec.greedy_run(first, max_new_tokens - 1, inputs_embeds.shape[1], eos_token_id)
+            ids = torch.cat([first, rest])[None]
+            dec.check_chain()
+            if eos_token_id is not None:
+                hit = (ids[0] == eos_token_id).nonzero()
+                if hit.numel():
+                    ids = ids[:, : int(hit[0]) + 1]
+            return ids
         new_tokens = []
         done = torch.zeros(inputs_embeds.shape[0], dtype=torch.bool, device=inputs_embeds.device)
         for i in range(max_new_tokens):
@@ -396,6 +408,8 @@ class HipDecoder(StaticDecoder):
     # the attention launch ends at its split partials and the o-projection merges them under its first weight trip (bit-identical to
     # the fused attention launch + the plain o-projection; 4.8 us per layer faster): default; MERV_DECODE_SPLIT_MERGE=0 restores them
     use_split_merge = os.environ.get("MERV_DECODE_SPLIT_MERGE", "1") != "0"
+    # greedy generation with the argmax / token hand-over / position increment inside the captured step; MERV_DECODE_GREEDY_GRAPH=0: host loop
+    use_greedy_graph = os.environ.get("MERV_DECODE_GREEDY_GRAPH", "1") != "0"
 
     @staticmethod
     def chain_supported(hf_model) -> bool:
@@ -555,6 +569,53 @@ class HipDecoder(StaticDecoder):
             last = torch.empty(1, D, dtype=self.dt, device=self.dev)
             rms(x[S - 1:], m.model.norm.weight, last, 1)
             return F.linear(last, m.lm_head.weight).float()
+
+    # Greedy decoding with nothing but the graph replay per token: the captured step ends with merv_decode_greedy_advance (argmax ->
+    # next token, token log, position + 1, all on the device) instead of the host loop's argmax / copy / add kernels (23 us per token).
+    greedy_graph = None
+    GREEDY_CHUNK = 8
+
+    @torch.inference_mode()
+    def greedy_run(self, token: torch.Tensor, steps: int, start: int, eos_token_id: Optional[int] = None) -> torch.Tensor:
+        """token [1]: the token at position `start` (= self.pos). Runs up to `steps` decode steps, each choosing its successor by
+        argmax; returns their tokens [n] (int64, device), n <= steps: with an `eos_token_id` the host looks every 8 steps and stops
+        after the chunk that produced it."""
+        from ._lib import check, ptr
+        if steps <= 0:
+            return torch.empty(0, dtype=torch.long, device=self.dev)
+        if self.greedy_graph is None:
+            self.tok = token[:, None].clone()
+            self.out_tokens = torch.zeros(self.max_len, dtype=torch.long, device=self.dev)  # token chosen AT position p (for p + 1)
+            self._step()  # warm-up outside the capture; the advance is not run: it would move the position
+            torch.cuda.synchronize(self.dev)
+
+            def capture(nsteps):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(nsteps):
+                        self._step()
+                        check(self.lib.merv_decode_greedy_advance(ptr(self.logits32), self.cfg.vocab_size, ptr(self.tok), ptr(self.pos),
+                                                                  ptr(self.out_tokens), 0, torch.cuda.current_stream(self.dev).cuda_stream),
+                              "merv_decode_greedy_advance")
+                return g
+            # GREEDY_CHUNK steps per replay as well as one: between two replays the GPU idles ~25 us (measured: the host loop's
+            # three small kernels per token had been hiding in that gap), a chunk pays it once
+            self.greedy_graph = capture(1)
+            self.greedy_graph_chunk = capture(self.GREEDY_CHUNK)
+        else:
+            self.tok.copy_(token[:, None])
+        done = 0
+        while done < steps:
+            if steps - done >= self.GREEDY_CHUNK:
+                self.greedy_graph_chunk.replay()
+                done += self.GREEDY_CHUNK
+            else:
+                self.greedy_graph.replay()
+                done += 1
+            if eos_token_id is not None and (done % self.GREEDY_CHUNK == 0 or done == steps):  # one host look per chunk
+                if bool((self.out_tokens[start:start + done] == eos_token_id).any()):
+                    break
+        return self.out_tokens[start:start + done].clone()
 
     def _step(self):
         from ._lib import check, ptr

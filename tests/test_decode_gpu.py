@@ -497,6 +497,59 @@ def test_hip_prefill_matches_pytorch_prefill(dev, kv_heads, family):
     assert rel_l2(b, a) < 2e-2
 
 
+def test_greedy_advance_kernel_follows_torch_argmax(dev):
+    """merv_decode_greedy_advance: token = torch.argmax(logits) -- first of tied maxima, a NaN wins --, logged at out[pos - pos0], pos + 1."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for case in range(6):
+        V = [32000, 32064, 320, 1, 151936, 5000][case]
+        lg = torch.randn(V, generator=g)
+        if case == 1:
+            lg[[17, 9000, 31000]] = 9.0       # tied maxima: the first wins
+        if case == 2:
+            lg[:] = -float("inf")              # all equal
+        if case == 5:
+            lg[[4000, 77]] = float("nan")      # NaN wins, the first one
+        lg = lg.to(dev)
+        tok = torch.full((1, 1), -1, dtype=torch.long, device=dev)
+        pos = torch.tensor([40 + case], dtype=torch.long, device=dev)
+        out = torch.full((64,), -1, dtype=torch.long, device=dev)
+        check(lib.merv_decode_greedy_advance(ptr(lg), V, ptr(tok), ptr(pos), ptr(out), 38, _st(dev)), "greedy_advance")
+        want = int(torch.argmax(lg))
+        assert int(tok) == want and int(pos) == 41 + case and int(out[2 + case]) == want and int((out != -1).sum()) == 1, case
+
+
+@pytest.mark.parametrize("eos", [None, "hit"])
+def test_greedy_generation_on_the_device_equals_the_host_loop(dev, eos):
+    """generate_from_embeds(do_sample=False) with the argmax / token hand-over / position increment inside the captured step
+    (HipDecoder.greedy_run) returns the host loop's tokens, with and without an EOS that stops it."""
+    from merv_amd.llm import HipDecoder, LlamaBackbone
+    llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                             num_key_value_heads=2, max_position_embeddings=2048, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
+    emb = (torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(7)) * 0.5).to(torch.bfloat16).to(dev)
+    assert HipDecoder.use_greedy_graph
+    try:
+        HipDecoder.use_greedy_graph = False
+        ref = llm.generate_from_embeds(emb, max_new_tokens=21)
+        llm._decoders.clear()
+        HipDecoder.use_greedy_graph = True
+        eos_id = int(ref[0, 10]) if eos else None
+        HipDecoder.use_greedy_graph = False
+        ref = llm.generate_from_embeds(emb, max_new_tokens=21, eos_token_id=eos_id)
+        llm._decoders.clear()
+        HipDecoder.use_greedy_graph = True
+        out = llm.generate_from_embeds(emb, max_new_tokens=21, eos_token_id=eos_id)
+        out2 = llm.generate_from_embeds(emb, max_new_tokens=21, eos_token_id=eos_id)  # the captured graph again, from a fresh prefill
+    finally:
+        HipDecoder.use_greedy_graph = True
+    assert isinstance(next(iter(llm._decoders.values())), HipDecoder)
+    assert torch.equal(out, ref) and torch.equal(out2, ref)
+    if eos:
+        assert int(out[0, -1]) == eos_id and out.shape[1] <= 11
+
+
 def test_generate_uses_hip_decoder_when_it_can(dev):
     from merv_amd.llm import HipDecoder, LlamaBackbone, StaticDecoder
     llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
