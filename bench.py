@@ -189,12 +189,18 @@ def e2e_generate(bbs, extras, device, new_tokens=64):
             torch.cuda.synchronize(); t0 = time.perf_counter(); lg = dec.prefill(emb); torch.cuda.synchronize()
             t_prefill = min(t_prefill, time.perf_counter() - t0)
         tok = lg.argmax(-1)
-        for _ in range(3):
-            dec.decode(tok)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(32):
-            dec.decode(tok)
-        torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
+        if getattr(dec, "use_greedy_graph", False):  # what generate() runs: greedy steps chosen on the device, 8 per graph replay
+            dec.greedy_run(tok, 8, n_pre)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            dec.greedy_run(tok, 32, n_pre + 8)
+            torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
+        else:
+            for _ in range(3):
+                dec.decode(tok)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(32):
+                dec.decode(tok)
+            torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / 32
     hip_prefill = type(dec).__name__ == "HipDecoder" and getattr(dec, "use_hip_prefill", False)
     res = {"what": "quick_start-shaped generate(): merv-full geometry, Llama-2-7B geometry bf16 random init; prefill: "
                    + ("PyTorch-ROCm library GEMMs + libmerv_hip.so kernels for RMSNorm / rotary + cache fill / causal attention / silu * up"
