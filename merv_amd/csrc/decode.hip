@@ -1,7 +1,7 @@
 // Batch-1 token decode kernels for the LLM hand-off (merv/models/vidlms/merv.py:818-825 ->
 // HF GenerationMixin's per-token forward of LlamaForCausalLM / MistralForCausalLM, transformers modeling_llama).
 //
-// The north_star keeps the LLM *prefill* on PyTorch-ROCm. A decode step, though, is ~1100 tiny PyTorch kernels per token
+// The north_star keeps the LLM on PyTorch-ROCm; the e2e half of the metric moved two things here. (1) A decode step is ~1100 tiny PyTorch kernels per token
 // (RMSNorm = 8 launches, rotary embedding = 10, ...): measured on MI355X, 6.1 of the 10.4 ms of a graph-replayed
 // Llama-2-7B step are those launches, 4.7 ms the library's M = 1 GEMMs at 2.4-3.4 TB/s (tools/probes/decode_breakdown.py).
 // These kernels are the step as 5 launches per layer (7 through the separate rotary / attention / merge entry points), every one
@@ -13,6 +13,11 @@
 //   rope_cache_kernel      q, k <- rotary(pos); K / V cache[pos] <- k, v              (apply_rotary_pos_emb + cache update)
 //   decode_attn_kernel     one query per head against cache[0 .. pos], split over positions, (m, l, o) partials
 //   decode_attn_merge_kernel  merges the partials                                      (flash-decoding)
+//   decode_attn_split_kernel + oproj_merge_kernel   the default pair since round 4: rotary + cache + split attention ending at the
+//                          partials, and the o-projection that merges them under its first weight trip
+//   greedy_advance_kernel  argmax -> next token, token log, position + 1 inside the captured step (greedy search)
+// (2) The prompt prefill keeps its GEMMs on the library and takes everything between them from here and attention.hip:
+//   rmsnorm_kernel (rows = S), add_rmsnorm_kernel, prefill_rope_cache_kernel, silu_mul_kernel, prefill_attn_kernel
 //
 // Rounding points follow the bf16 module: every nn.Linear output, every elementwise result is rounded to bf16 where the
 // PyTorch graph materialises a bf16 tensor; accumulation and softmax are fp32. The position is read from device memory

@@ -363,7 +363,8 @@ class HipDecoder(StaticDecoder):
     -- the q / k / v projections as one GEMV launch with the input RMSNorm fused in, rotary + cache update + split attention + merge as one launch, o-projection with the residual, the
     gated MLP as one GEMV pair with its RMSNorm and silu * up fused, down-projection with the residual -- instead of ~35 PyTorch ones, each a
     pure HBM stream (weights read once, non-temporal). Same parameters (the HF module's, no copies), same static cache and
-    rotary tables, same rounding points as the bf16 module; prefill stays on PyTorch-ROCm (north_star). Measured on MI355X
+    rotary tables, same rounding points as the bf16 module; the prefill keeps its GEMMs on PyTorch-ROCm and takes the rest from the
+    library too (`_prefill_fused`). Measured on MI355X
     with Llama-2-7B geometry: see DESIGN.md section 6 (e2e)."""
 
     NSPLIT = 8  # position ranges per head in decode attention: 32 heads x 8 = one block per CU
