@@ -464,7 +464,7 @@ def test_hip_prefill_matches_pytorch_prefill(dev, kv_heads, family):
                 for pr in (lyr.self_attn.q_proj, lyr.self_attn.k_proj, lyr.self_attn.v_proj):
                     pr.bias.normal_(0, 0.5)
     ref, hip = StaticDecoder(llm.llm, 256, 1), HipDecoder(llm.llm, 256, 1)
-    assert hip.use_hip_prefill
+    hip.use_hip_prefill = hip.use_hip_prefill_attn = True  # (the defaults; MERV_HIP_PREFILL=0 in the environment would switch them off)
     emb = (torch.randn(1, 77, 256, generator=torch.Generator().manual_seed(4)) * 0.5).to(torch.bfloat16).to(dev)
     emb0 = emb.clone()
     sd0 = {k: v.clone() for k, v in llm.llm.state_dict().items()}
@@ -529,7 +529,7 @@ def test_greedy_generation_on_the_device_equals_the_host_loop(dev, eos):
     llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
                              num_key_value_heads=2, max_position_embeddings=2048, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
     emb = (torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(7)) * 0.5).to(torch.bfloat16).to(dev)
-    assert HipDecoder.use_greedy_graph
+    was = HipDecoder.use_greedy_graph
     try:
         HipDecoder.use_greedy_graph = False
         ref = llm.generate_from_embeds(emb, max_new_tokens=21)
@@ -543,7 +543,7 @@ def test_greedy_generation_on_the_device_equals_the_host_loop(dev, eos):
         out = llm.generate_from_embeds(emb, max_new_tokens=21, eos_token_id=eos_id)
         out2 = llm.generate_from_embeds(emb, max_new_tokens=21, eos_token_id=eos_id)  # the captured graph again, from a fresh prefill
     finally:
-        HipDecoder.use_greedy_graph = True
+        HipDecoder.use_greedy_graph = was
     assert isinstance(next(iter(llm._decoders.values())), HipDecoder)
     assert torch.equal(out, ref) and torch.equal(out2, ref)
     if eos:
