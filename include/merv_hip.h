@@ -27,8 +27,10 @@
 extern "C" {
 #endif
 
-/* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged */
-#define MERV_ABI_VERSION 2
+/* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
+ * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
+ *    section 5) are no longer exported; every other entry point unchanged */
+#define MERV_ABI_VERSION 3
 
 /* activation kinds */
 enum { MERV_ACT_NONE = 0, MERV_ACT_GELU_ERF = 1, MERV_ACT_GELU_TANH = 2, MERV_ACT_QUICK_GELU = 3 };
@@ -395,51 +397,6 @@ int merv_decode_oproj_merge(const void *Wo, const void *res, void *y, const floa
  * wins), out_tokens[*pos - pos0] <- the token (out_tokens may be NULL), *pos += 1 -- so that a replayed step leaves the next step's
  * token and position on the device and the host loop launches nothing else per token. */
 int merv_decode_greedy_advance(const float *logits, int32_t V, int64_t *tok, int64_t *pos, int64_t *out_tokens, int64_t pos0, void *stream);
-/* merv_decode_attention_fused and the o-projection with its residual, x[D] += Wo[D, H*hd] . attention, as ONE launch (bit-identical
- * to the two calls): one workgroup per (head, position range) whose second half -- four loader waves -- brings its 16 rows of Wo into
- * LDS while the first half runs the attention, so the o-projection's weight stream hides under the attention's latency chain. `out`
- * still receives the attention output. Requires D == 16 * H * nsplit (nsplit = 8 for hd = 128) and H * hd <= 4608.
- * counters: merv_decode_attn_oproj_counter_bytes() bytes of device memory (zero before the first call; every launch restores them);
- * err: one device word, OR-ed when an in-launch wait gives up after 0.2 s (results invalid). */
-size_t merv_decode_attn_oproj_counter_bytes(void);
-int merv_decode_attn_oproj(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
-                           void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
-                           int32_t nsplit, float scale, const void *Wo, void *x, int32_t D, void *counters, uint32_t *err, void *stream);
-
-/*
- * The whole decode step -- every layer's five operations and the final norm + lm_head -- as ONE launch (round 4): the operations are
- * block ranges of one grid in dependency order; a block requests its first weights, then waits on its producer's arrival counter
- * (write-through hand-off, bounded spins), so the HBM weight stream does not stop at operation boundaries. Same arithmetic, rounding
- * points and reduction orders as the calls above: the logits are bit-identical to the 5-launches-per-layer sequence. Replaces the same
- * reference code (merv/models/vidlms/merv.py:818-825 -> the per-token LlamaForCausalLM.forward).
- *   layers    device array of L merv_decode_layer entries (device pointers; bq / bk / bv may be NULL)
- *   x         [D] bf16, holds the token's embedding on entry (it is the residual stream of the step)
- *   counters  merv_decode_chain_counter_bytes(L) bytes of device memory, zeroed by every call (a memset on the stream)
- *   err       one device word, only ever OR-ed: non-zero after a step means a wait gave up after 0.2 s (results invalid)
- * Requirements: hd == 128; H*hd, Hkv*hd, D, I, V multiples of 8; 512 <= D <= 8192; no o_proj / MLP biases.
- */
-typedef struct merv_decode_layer {
-    const void *wq, *wk, *wv, *wo, *wg, *wu, *wd;  /* nn.Linear weights [out, in] bf16 */
-    const void *ln1, *ln2;                         /* input_layernorm / post_attention_layernorm weights [D] bf16 */
-    const void *bq, *bk, *bv;                      /* q / k / v biases bf16 or NULL */
-    void *k_cache, *v_cache;                       /* [Hkv, max_len, hd] bf16 */
-} merv_decode_layer;
-typedef struct merv_decode_chain {
-    const merv_decode_layer *layers;
-    int32_t L, D, I, H, Hkv, hd, V, max_len, nsplit;
-    void *x, *q, *k, *v, *ao, *mid;                /* [D], [H hd], [Hkv hd], [Hkv hd], [H hd], [I] bf16 */
-    float *logits;                                 /* [V] */
-    const void *cos_t, *sin_t;                     /* [max_len, hd] bf16 */
-    const int64_t *pos;                            /* device int64 */
-    float *attn_ws;                                /* merv_decode_attention_fused_workspace_floats(H, nsplit) floats, zeroed once */
-    const void *final_norm, *lm_head;              /* [D], [V, D] bf16 */
-    void *counters;
-    uint32_t *err;
-    float eps, scale;
-} merv_decode_chain;
-size_t merv_decode_chain_counter_bytes(int32_t layers);
-int merv_decode_chain_step(const merv_decode_chain *c, void *stream);
-
 /* The attention step of timm's AttentionPoolLatent (global_pool='map': what the SigLIP ids without `all-no-cls` return,
  * siglip.py:46-63): one learnt query per head against every token of a frame. kv [nseq*ntok, 2*D] bf16 = [k | v] rows (the kv
  * Linear's output), q [D] fp32 = q Linear of the latent, out [nseq, D] bf16; D = heads * 64, ntok <= 1024. */

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
@@ -53,15 +54,7 @@ class EncoderWeights(C.Structure):
 _i32, _i64, _f32, _f64, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
 
-class DecodeChain(C.Structure):
-    """include/merv_hip.h `merv_decode_chain`: the whole decode step as one launch (field order is the ABI)."""
-    _fields_ = ([("layers", C.c_void_p)] + [(n, C.c_int32) for n in ("L", "D", "I", "H", "Hkv", "hd", "V", "max_len", "nsplit")] +
-                [(n, C.c_void_p) for n in ("x", "q", "k", "v", "ao", "mid", "logits", "cos_t", "sin_t", "pos", "attn_ws", "final_norm",
-                                           "lm_head", "counters", "err")] + [("eps", C.c_float), ("scale", C.c_float)])
-
-
-DECODE_LAYER_FIELDS = ("wq", "wk", "wv", "wo", "wg", "wu", "wd", "ln1", "ln2", "bq", "bk", "bv", "k_cache", "v_cache")  # merv_decode_layer
-ABI_VERSION = 2  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
+ABI_VERSION = 3  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
 
 SIGNATURES = {
     "merv_last_error": (C.c_char_p, []),
@@ -124,10 +117,6 @@ SIGNATURES = {
     "merv_decode_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_oproj_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_decode_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _vp]),
-    "merv_decode_attn_oproj_counter_bytes": (_sz, []),
-    "merv_decode_attn_oproj": (C.c_int, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "merv_decode_chain_counter_bytes": (_sz, [_i32]),
-    "merv_decode_chain_step": (C.c_int, [_vp, _vp]),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_debug_set_attn_rescale_thr": (None, [_f32]),
     "merv_prof_enable": (None, [_i32]),
@@ -150,12 +139,20 @@ def load() -> C.CDLL:
             "merv_amd has no CPU fallback."
         )
     lib = C.CDLL(str(path))
+    # MERV_HIP_LIB names another build for same-box A/B pairs (tools/probes/ab_*.sh), possibly a previous round's: symbols that
+    # library lacks stay unbound (using one raises) and its ABI version is only reported. The product library is checked strictly.
+    ab_build = "MERV_HIP_LIB" in os.environ
     for name, (res, args) in SIGNATURES.items():
+        if ab_build and not hasattr(lib, name):
+            print(f"[merv_amd] A/B library {path} does not export {name}", file=sys.stderr)
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export the ABI
         fn.restype = res
         fn.argtypes = args
     if lib.merv_abi_version() != ABI_VERSION:
-        raise RuntimeError(f"libmerv_hip.so ABI version {lib.merv_abi_version()} != {ABI_VERSION} (stale build: run `make lib`)")
+        if not ab_build:
+            raise RuntimeError(f"libmerv_hip.so ABI version {lib.merv_abi_version()} != {ABI_VERSION} (stale build: run `make lib`)")
+        print(f"[merv_amd] A/B library {path}: ABI version {lib.merv_abi_version()} (binding written against {ABI_VERSION})", file=sys.stderr)
     _lib = lib
     return lib
 

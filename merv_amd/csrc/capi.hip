@@ -985,51 +985,6 @@ extern "C" int merv_decode_greedy_advance(const float* logits, int32_t V, int64_
     return 0;
 }
 
-extern "C" size_t merv_decode_attn_oproj_counter_bytes(void) { return decode_attn_oproj_counter_bytes(); }
-
-extern "C" int merv_decode_attn_oproj(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t, const int64_t* pos,
-                                      void* k_cache, void* v_cache, void* out, float* ws, int32_t H, int32_t Hkv, int32_t hd, int32_t max_len,
-                                      int32_t nsplit, float scale, const void* Wo, void* x, int32_t D, void* counters, uint32_t* err,
-                                      void* stream_) {
-    MERV_STREAM_DEVICE(stream_);
-    MERV_CHECK(q && k && v && cos_t && sin_t && pos && k_cache && v_cache && out && ws && Wo && x && counters && err,
-               "merv_decode_attn_oproj: null argument");
-    MERV_CHECK(hd == 128, "merv_decode_attn_oproj: head_dim must be 128");
-    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attn_oproj: bad geometry");
-    MERV_CHECK(D == 16 * H * nsplit && (H * hd) % 512 == 0 && H * hd <= 4608,
-               "merv_decode_attn_oproj: needs D == 16 * H * nsplit and H * hd a multiple of 512, at most 4608");
-    DecodeAttnOprojArgs a{};
-    a.a = DecodeAttnFusedArgs{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
-                              (bf16_t*)v_cache, (bf16_t*)out, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale};
-    a.Wo = (const bf16_t*)Wo; a.x = (bf16_t*)x; a.D = D; a.counters = (unsigned*)counters; a.err = err;
-    MERV_HIP(launch_decode_attn_oproj(a, (hipStream_t)stream_));
-    return 0;
-}
-
-extern "C" size_t merv_decode_chain_counter_bytes(int32_t layers) { return layers > 0 ? decode_chain_counter_bytes(layers) : 0; }
-
-extern "C" int merv_decode_chain_step(const merv_decode_chain* c, void* stream_) {
-    MERV_STREAM_DEVICE(stream_);
-    MERV_CHECK(c && c->layers && c->x && c->q && c->k && c->v && c->ao && c->mid && c->logits && c->cos_t && c->sin_t && c->pos && c->attn_ws &&
-                   c->final_norm && c->lm_head && c->counters && c->err,
-               "merv_decode_chain_step: null argument");
-    MERV_CHECK(c->hd == 128, "merv_decode_chain_step: head_dim must be 128");
-    MERV_CHECK(c->L > 0 && c->H > 0 && c->Hkv > 0 && c->H % c->Hkv == 0 && c->nsplit > 0 && c->nsplit <= 64 && c->max_len > 0,
-               "merv_decode_chain_step: bad geometry");
-    MERV_CHECK(c->D % 8 == 0 && c->D >= 512 && c->D <= 8192 && c->I % 8 == 0 && c->I >= 512 && c->V % 8 == 0 && c->V > 0,
-               "merv_decode_chain_step: D, I, V must be multiples of 8 with 512 <= D <= 8192");
-    static_assert(sizeof(merv_decode_layer) == sizeof(DecodeLayerW), "the ABI's layer entry is the kernel's");
-    DecodeChainArgs a{};
-    a.layers = (const DecodeLayerW*)c->layers;
-    a.L = c->L; a.D = c->D; a.I = c->I; a.H = c->H; a.Hkv = c->Hkv; a.hd = c->hd; a.V = c->V; a.max_len = c->max_len; a.nsplit = c->nsplit;
-    a.x = (bf16_t*)c->x; a.q = (bf16_t*)c->q; a.k = (bf16_t*)c->k; a.v = (bf16_t*)c->v; a.ao = (bf16_t*)c->ao; a.mid = (bf16_t*)c->mid;
-    a.logits = c->logits; a.cos = (const bf16_t*)c->cos_t; a.sin = (const bf16_t*)c->sin_t; a.pos = (const long*)c->pos; a.attn_ws = c->attn_ws;
-    a.final_norm = (const bf16_t*)c->final_norm; a.lm_head = (const bf16_t*)c->lm_head; a.counters = (unsigned*)c->counters; a.err = c->err;
-    a.eps = c->eps; a.scale = c->scale;
-    MERV_HIP(launch_decode_chain(a, (hipStream_t)stream_));
-    return 0;
-}
-
 extern "C" int merv_mean_rows(const void* x, void* out, int32_t groups, int32_t rows, int32_t D, int64_t group_stride_rows,
                               void* stream_) {
     MERV_STREAM_DEVICE(stream_);

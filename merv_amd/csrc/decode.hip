@@ -147,89 +147,16 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(DecodeRmsArgs p, const
     }
 }
 
-// ---- hand-off policies: how a kernel body meets the data other workgroups produce / consume ----
-// Stand-alone launches: inputs are complete before the launch starts and outputs are read after it ends.
-struct NoHandoff {
-    static constexpr bool chained = false;
-    MERV_DEVICE void wait_input(int) const {}
-    MERV_DEVICE u32x4 load16(const bf16_t* base, int elem, int) const { return *(const u32x4*)(base + elem); }
-    MERV_DEVICE float load_bf16(const bf16_t* base, int elem, int) const { return bf2f(base[elem]); }
-    MERV_DEVICE void signal() const {}
-};
-// One launch for the whole decode step (decode_chain_kernel): an operation's workgroups follow its producer's in block-index
-// order, request their first weights, and only then wait for the producer's arrival counter. The in-launch hand-off is the
-// write-through form of cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms" (first table row): every
-// handed-off byte is stored sc1 (4 / 8 bytes, relaxed agent-scope atomic stores) by ONE lane of its workgroup, which then waits
-// vmcnt(0) and adds to the operation's counter (agent-scope atomic); a consumer workgroup polls the counter with sc1 loads from
-// one wave, the others wait at a workgroup barrier that wave then joins, and EVERY load of handed-off bytes is an sc1 load
-// (buffer_load ... sc1 / relaxed agent-scope atomic loads) -- no release / acquire fences. Counters are zeroed by a memset
-// node ahead of the launch (one per step); every spin is bounded (a stuck chain sets *err and runs on, it never hangs).
-constexpr int CHAIN_SHARDS = 8;          // arrival counter shards per operation, one 128-byte line each
-constexpr int CHAIN_OP_STRIDE = CHAIN_SHARDS * 32;  // uint32 per operation
-struct ChainHandoff {
-    static constexpr bool chained = true;
-    const unsigned* dep;   // producer's counter shards (nullptr: inputs were complete before the launch)
-    unsigned expected;     // arrivals that complete the producer
-    unsigned* mine;        // this operation's counter shards (nullptr: nothing in this launch consumes the outputs)
-    unsigned* err;
-    int block;
-    MERV_DEVICE void wait_input(int wave) const {
-#ifdef MERV_CHAIN_ABL_NOWAIT  // ablation (wrong results): how fast does the merged grid stream without any hand-off?
-        return;
-#endif
-        if (dep == nullptr) return;  // (uniform)
-        if (wave == 0) {
-            const int lane = threadIdx.x & 63;
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-            for (;;) {
-                unsigned v = lane < CHAIN_SHARDS ? __hip_atomic_load(dep + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-                for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                if (__builtin_amdgcn_readfirstlane(v) >= expected) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull) {  // 0.2 s: the chain is stuck -- report, do not hang
-                    if (lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-    }
-    MERV_DEVICE u32x4 load16(const bf16_t* base, int elem, int total_elems) const {
-#ifdef MERV_CHAIN_ABL_PLAINX  // ablation (stale reads possible): the input vector through L1 like the stand-alone kernels
-        return *(const u32x4*)(base + elem);
-#endif
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, total_elems * 2, 0x00020000);
-        return __builtin_amdgcn_raw_buffer_load_b128(r, elem * 2, 0, 16);  // aux 16 = sc1
-    }
-    MERV_DEVICE float load_bf16(const bf16_t* base, int elem, int total_elems) const {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, total_elems * 2, 0x00020000);
-        return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, elem * 2, 0, 16));
-    }
-    // by the ONE lane that stored this workgroup's outputs, right after those stores
-    MERV_DEVICE void signal() const {
-        if (mine == nullptr) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(mine + (block & (CHAIN_SHARDS - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-};
-MERV_DEVICE void store_sc1_u64(void* ptr, unsigned long long v) {
-    __hip_atomic_store((unsigned long long*)ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ---- GEMV: W [N, K] bf16 row-major streamed once; each wave owns ROWS output rows, lanes stride K in 16-byte chunks ----
 constexpr int GEMV_WAVES = 4;  // waves per block
 struct GemvLds {
     float norm_part[GEMV_WAVES];
-    bf16_t out_stage[GEMV_WAVES * 2];  // chained launches: the block's outputs, stored by one lane
 };
 
 // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in; GEMV_ROWS: output rows per wave (the x chunk
-// is reused across them). `block`: this workgroup's index within the operation. Chained: every row count is a multiple of
-// GEMV_WAVES * GEMV_ROWS (no idle waves, a block's rows lie in one matrix) and the outputs are bf16 (the logits' consumer is
-// the host).
-template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS, class HO>
-MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, const HO& ho) {
+// is reused across them). `block`: this workgroup's index.
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS>
+MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
     int n0 = (block * GEMV_WAVES + wave) * GEMV_ROWS;
@@ -244,7 +171,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
     static_assert(GEMV_WAVES == 4, "the fused norm splits the row's sum of squares over the block's four waves");
     // a wave past the last row still takes part in the fused norm's block-wide reduction (and then leaves)
     const bool idle = n0 >= p.N;
-    if (idle && !NORM && !HO::chained) return;
+    if (idle && !NORM) return;
     const int nchunk = p.K >> 3;
     float acc[NW_MATS][GEMV_ROWS];
 #pragma unroll
@@ -279,35 +206,21 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
-            xv[u] = ho.load16(p.x, cu * 8, p.K);
+            xv[u] = *(const u32x4*)(p.x + cu * 8);
             if constexpr (NORM) nv[u] = *(const u32x4*)(p.norm_w + cu * 8);
         }
     };
     // fused RMSNorm: the BLOCK reduces mean(x^2) over the whole input once (8 KB, L2-resident; a quarter per wave) and every wave
-    // normalises the chunks it multiplies. Stand-alone: the norm's chunks are requested FIRST (vmcnt is in order: they return
-    // first) and the whole first trip before anything waits for them. Chained: the first trip's WEIGHTS are requested before the
-    // wait for the producer -- that is what keeps the HBM stream going across operations -- and everything that reads x after it.
+    // normalises the chunks it multiplies. The norm's chunks are requested FIRST (vmcnt is in order: they return first) and the
+    // whole first trip before anything waits for them.
     int c = lane;
     u32x4 nx[4];
-    if constexpr (HO::chained) {
-        issue_w(c);
-        ho.wait_input(wave);
-        if constexpr (NORM) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cc = lane + 64 * wave + 256 * i;
-                nx[i] = cc < nchunk ? ho.load16(p.x, cc * 8, p.K) : u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-        issue_x(c);
-    } else {
-        if constexpr (NORM) sumsq_request(p.x, nchunk, lane, wave, nx);
-        // unconditional (idle waves of the last block re-read a valid row, lanes past a short row's end a valid chunk): behind a
-        // branch hipcc's waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip
-        issue_w(c);
-        issue_x(c);
-        __builtin_amdgcn_sched_barrier(0);  // the whole first trip is requested before anything waits for the norm's chunks
-    }
+    if constexpr (NORM) sumsq_request(p.x, nchunk, lane, wave, nx);
+    // unconditional (idle waves of the last block re-read a valid row, lanes past a short row's end a valid chunk): behind a
+    // branch hipcc's waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip
+    issue_w(c);
+    issue_x(c);
+    __builtin_amdgcn_sched_barrier(0);  // the whole first trip is requested before anything waits for the norm's chunks
     float rstd = 0.f;
     if constexpr (NORM) {
         const float part = sumsq_finish(p.x, nchunk, lane, wave, nx);  // (K <= 8192: no load inside)
@@ -358,26 +271,10 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
                 const float s = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor
                 v = s * round_bf(acc[1][r]);
             } else if (p.res) {
-                v = v + ho.load_bf16(p.res, n, p.N);  // x + linear(...), rounded once more below
+                v = v + bf2f(p.res[n]);  // x + linear(...), rounded once more below
             }
             if (p.y32) p.y32[n] = v;  // logits: .float() of the bf16 linear output
-            else if constexpr (HO::chained) lds.out_stage[wave * GEMV_ROWS + r] = f2bf(v);
             else p.y[n] = f2bf(v);
-        }
-    }
-    if constexpr (HO::chained) {
-        if (p.y32) return;  // (uniform) the host reads the logits after the launch
-        __syncthreads();
-        if (threadIdx.x == 0) {  // the block's GEMV_WAVES * GEMV_ROWS consecutive outputs: 8 bytes per store, write-through
-            bf16_t* dst = p.y + n0;  // thread 0 is in wave 0: n0 is the block's first row (in its own matrix)
-#pragma unroll
-            for (int q = 0; q < GEMV_WAVES * GEMV_ROWS / 4; ++q) {
-                unsigned long long w = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w |= (unsigned long long)lds.out_stage[4 * q + j] << (16 * j);
-                store_sc1_u64(dst + 4 * q, w);
-            }
-            ho.signal();
         }
     }
 }
@@ -385,7 +282,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, cons
 template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     __shared__ GemvLds lds;
-    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds, NoHandoff{});
+    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds);
 }
 
 // ---- rotary embedding of q and k at the current position + cache update ----
@@ -618,14 +515,12 @@ struct AttnLds {
     __attribute__((aligned(16))) float o[16][128];
     unsigned ticket;
 };
-// h: head, s: position range. Chained: q / k / v are the q / k / v operation's outputs (sc1 loads behind the wait), the merged
-// head goes out as 4-byte write-through stores and EVERY block adds to the operation's counter when it is done -- the merging
-// block of a head after its output stores, so H * nsplit arrivals mean every head is merged.
+// h: head, s: position range.
 // SPLIT_ONLY (round 4, stand-alone launch): the launch ends at the partials -- written with plain stores, visible at the kernel
 // boundary -- and the o-projection launch merges them while its first weight trip is in flight (oproj_merge_kernel): no write-through,
 // no vmcnt(0) + barrier + ticket round trip, no second pass over the partials inside this launch's dependency chain (9.0 against 13.8 us).
-template <class HO, bool SPLIT_ONLY = false>
-MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, const int s, AttnLds& lds, const HO& ho) {
+template <bool SPLIT_ONLY>
+MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, const int s, AttnLds& lds) {
     const int grp_heads = p.H / p.Hkv;
     const int hkv = h / grp_heads;
     const long pos = *p.pos;
@@ -639,9 +534,8 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
     float cf[8], sf[8];
     unpack8f(*(const u32x4*)(p.cos + pos * 128 + sub * 8), cf);
     unpack8f(*(const u32x4*)(p.sin + pos * 128 + sub * 8), sf);
-    ho.wait_input(__builtin_amdgcn_readfirstlane(wave));
     auto rotary = [&](const bf16_t* base, int off, int total, float (&r)[8]) {
-        const u32x4 own = ho.load16(base, off + sub * 8, total);
+        const u32x4 own = *(const u32x4*)(base + (off + sub * 8));
         u32x4 oth;
 #pragma unroll
         for (int q = 0; q < 4; ++q) oth[q] = __shfl_xor(own[q], 8, 64);
@@ -665,7 +559,7 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
     if (pos >= j0 && pos < j1 && g == (int)((pos - j0) & 15)) {  // uniform per 16-lane group: the shuffles inside stay in the group
         float kf[8], vf[8];
         rotary(p.k, hkv * 128, p.Hkv * 128, kf);
-        const u32x4 vraw = ho.load16(p.v, hkv * 128 + sub * 8, p.Hkv * 128);
+        const u32x4 vraw = *(const u32x4*)(p.v + (hkv * 128 + sub * 8));
         unpack8f(vraw, vf);
         da_one(st, qf, kf, vf, sc);
         if (h % grp_heads == 0) {
@@ -727,10 +621,7 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
     unsigned* counter = (unsigned*)(p.ws + (size_t)p.H * p.nsplit * (128 + 2)) + h * 32;  // one 128-byte line per head
     if (threadIdx.x == 0) lds.ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (lds.ticket != (unsigned)(p.nsplit - 1)) {
-        if (threadIdx.x == 0) ho.signal();  // (chained) done, nothing more to publish
-        return;
-    }
+    if (lds.ticket != (unsigned)(p.nsplit - 1)) return;
     if (threadIdx.x < 128) {
         const int d = threadIdx.x;
         auto ld = [&](int i) { return __hip_atomic_load(ws_h + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -743,30 +634,18 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
             L = fmaf(w, ld(q * 130 + 129), L);
             O = fmaf(w, ld(q * 130 + d), O);
         }
-        const bf16_t ob = f2bf(O / L);
-        if constexpr (HO::chained) {  // pairs of dims as one 4-byte write-through store
-            const unsigned hi = __shfl_down((unsigned)ob, 1, 64);
-            if ((d & 1) == 0)
-                __hip_atomic_store((unsigned*)(p.out + h * 128 + d), (unsigned)ob | (hi << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            p.out[h * 128 + d] = ob;
-        }
+        p.out[h * 128 + d] = f2bf(O / L);
     }
     if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (HO::chained) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave (waves 0 and 1), then ONE lane signals
-        __syncthreads();
-        if (threadIdx.x == 0) ho.signal();
-    }
 }
 
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAttnFusedArgs p) {
     __shared__ AttnLds lds;
-    attn_fused_body(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
+    attn_fused_body<false>(p, blockIdx.x, blockIdx.y, lds);
 }
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_split_kernel(DecodeAttnFusedArgs p) {
     __shared__ AttnLds lds;
-    attn_fused_body<NoHandoff, true>(p, blockIdx.x, blockIdx.y, lds, NoHandoff{});
+    attn_fused_body<true>(p, blockIdx.x, blockIdx.y, lds);
 }
 
 // ---- greedy decoding inside the captured step: token = argmax(logits) (torch.argmax's rule: the first maximum; a NaN wins), ----
@@ -938,183 +817,6 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Attention + o-projection as ONE launch (round 4). The attention launch is a 14 us chain of dependent memory round trips over
-// 17 MB of cache -- the HBM pipe idles -- and the o-projection behind it streams 33.5 MB in 8 us. Here every workgroup (one per
-// CU: head h, position range s, as in the fused attention launch) has a second half of four LOADER waves that bring the
-// workgroup's 16 rows of W_o into LDS by LDS-DMA (128 KB per CU at D = 4096: the whole matrix sits in the chip's LDS) while
-// waves 0-3 run the attention; the attention outputs are handed over in-launch (write-through stores + arrival counter, as in
-// the chain kernel below), and all eight waves finish x += W_o . attention from LDS. The weight stream costs no time of its own.
-// vmcnt is one in-order counter per wave, so the DMA cannot ride in the attention waves (every attention load would wait for
-// the DMAs queued before it): hence the loader waves; they mirror the attention body's workgroup barriers.
-// Counters (per layer): the arrival shards and a departure word; the workgroup that leaves last (every workgroup has passed the
-// wait by then) zeroes them, so the launch leaves its counters as it found them and a captured graph replays at any position.
-// Same arithmetic and reduction order as the separate launches: bit-identical.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int AO_ROWS = 16;  // W_o rows per workgroup
-__global__ __launch_bounds__(512) void decode_attn_oproj_kernel(DecodeAttnOprojArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char wbuf[];  // [AO_ROWS][K] bf16, lane-linear 1-KiB pieces
-    __shared__ AttnLds alds;
-    __shared__ bf16_t out16[AO_ROWS];
-    const int bid = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int K = p.a.H * 128, npc = K >> 9;  // 512-element pieces per row
-    const int nblocks = p.a.H * p.a.nsplit;
-    unsigned* cnt = p.counters;                          // arrival shards
-    unsigned* departed = p.counters + CHAIN_OP_STRIDE;   // workgroups that are past the wait and done
-    if (wave >= 4) {  // loader waves: rows 4 (wave - 4) .. + 3 of the workgroup's 16
-        const int r0 = 4 * (wave - 4);
-        auto load_rows = [&](int ra, int rb) {
-            for (int r = ra; r < rb; ++r) {
-                const bf16_t* src = p.Wo + (size_t)(bid * AO_ROWS + r) * K + lane * 8;
-                for (int pc = 0; pc < npc; ++pc)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pc * 512),
-                                                     (__attribute__((address_space(3))) void*)(wbuf + ((size_t)r * K + pc * 512) * 2), 16, 0, 0);
-            }
-        };
-        // the attention body's three workgroup barriers (a fourth in the head's merging workgroup): raw, nothing to wait for yet.
-        // MERV_AO_LOADER_LATE: the weight stream starts behind the first barrier (the attention's cache rows are through), half
-        // of it behind the second -- from the launch's start it competes with the attention's loads for the CU's memory path
-#ifdef MERV_AO_LOADER_LATE
-        __builtin_amdgcn_s_barrier();
-        load_rows(r0, r0 + 2);
-        __builtin_amdgcn_s_barrier();
-        load_rows(r0 + 2, r0 + 4);
-        __builtin_amdgcn_s_barrier();
-#else
-        load_rows(r0, r0 + 4);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-#endif
-        asm volatile("" ::: "memory");  // (the ticket was written before the third barrier: do not read it earlier)
-        if (*(volatile unsigned*)&alds.ticket == (unsigned)(p.a.nsplit - 1)) __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's rows have landed (before the barrier inside wait_input)
-    } else {
-        ChainHandoff ho;
-        ho.dep = nullptr; ho.expected = 0; ho.mine = cnt; ho.err = p.err; ho.block = bid;
-        attn_fused_body(p.a, bid % p.a.H, bid / p.a.H, alds, ho);
-    }
-    ChainHandoff hw;
-    hw.dep = cnt; hw.expected = (unsigned)nblocks; hw.mine = nullptr; hw.err = p.err; hw.block = bid;
-    hw.wait_input(wave);  // every head is merged and published; (barrier inside) every loader wave's rows are in LDS
-    // x[n] += W_o[n, :] . attention, rows 16 bid + 2 wave, + 1: chunks lane, lane + 64, ... in order, as gemv_body
-    float acc[2] = {0.f, 0.f};
-    for (int pc = 0; pc < npc; ++pc) {
-        float xf[8];
-        unpack8f(hw.load16(p.a.out, (pc * 64 + lane) * 8, K), xf);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float wf[8];
-            unpack8f(*(const u32x4*)(wbuf + ((size_t)(2 * wave + r) * K + pc * 512) * 2 + lane * 16), wf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[r] = fmaf(wf[j], xf[j], acc[r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) acc[r] = wave_sum64(acc[r]);
-    if (lane == 0) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int n = bid * AO_ROWS + 2 * wave + r;
-            const float v = round_bf(acc[r]) + hw.load_bf16(p.x, n, nblocks * AO_ROWS);  // x + linear(...), rounded once more
-            out16[2 * wave + r] = f2bf(v);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < AO_ROWS / 4) {  // 8 bytes per lane: the next launch reads x after this one has ended
-        unsigned long long w = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w |= (unsigned long long)out16[4 * threadIdx.x + j] << (16 * j);
-        *(unsigned long long*)(p.x + bid * AO_ROWS + 4 * threadIdx.x) = w;
-    }
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(nblocks - 1)) {
-#pragma unroll
-        for (int i = 0; i < CHAIN_SHARDS; ++i) __hip_atomic_store(cnt + i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// The whole decode step as ONE launch (round 4). Five launches per layer each cost ~2.5 us of boundary, ramp and drain beside
-// their HBM stream (t = 2.5 us + bytes / 5.9 TB/s fits all four GEMV classes) and the attention launch is a 14 us latency chain
-// over 17 MB. Here the operations of all layers (and the lm_head) are block ranges of one grid, in dependency order. The
-// hardware hands out workgroups in index order, so when the last blocks of an operation are running, the blocks of the next one
-// are already resident behind them: they have requested their first weights (everything a block needs besides the producer's
-// output vector) and wait on the producer's arrival counter -- the HBM stream does not stop at an operation boundary.
-// Progress: every block waits only on blocks of LOWER index, and the lowest-index unfinished block of the grid is resident
-// (in-order dispatch per XCD), so it can always run; if that premise ever failed, the bounded spin reports through *err.
-// Arithmetic, rounding points and reduction orders are those of the separate kernels (same body functions): bit-identical.
-// ---------------------------------------------------------------------------------------------------------
-// (chunks per lane and trip, rows per wave) of each operation's blocks; a row's accumulation order does not depend on them
-#ifndef MERV_CHAIN_CFG
-#define MERV_CHAIN_CFG 4, 2, 4, 2, 4, 1, 4, 2
-#endif
-constexpr int CHAIN_CFG[8] = {MERV_CHAIN_CFG};  // qkv + lm_head, o_proj, gate / up, down_proj
-constexpr int CQ_UN = CHAIN_CFG[0], CQ_ROWS = CHAIN_CFG[1], CO_UN = CHAIN_CFG[2], CO_ROWS = CHAIN_CFG[3];
-constexpr int CG_UN = CHAIN_CFG[4], CG_ROWS = CHAIN_CFG[5], CD_UN = CHAIN_CFG[6], CD_ROWS = CHAIN_CFG[7];
-
-__global__ __launch_bounds__(DA_THREADS) void decode_chain_kernel(DecodeChainArgs c) {
-    static_assert(DA_THREADS == GEMV_WAVES * 64, "one block shape for every operation");
-    __shared__ union { GemvLds g; AttnLds a; } lds;
-    const int bpl = c.nb_qkv + c.nb_attn + c.nb_o + c.nb_gu + c.nb_down;
-    const int bid = blockIdx.x;
-    const int layer = bid / bpl;  // == c.L: the lm_head
-    int r = bid - layer * bpl;
-    auto counter = [&](int op) { return c.counters + (size_t)op * CHAIN_OP_STRIDE; };
-    ChainHandoff ho;
-    ho.err = c.err;
-    const int HD = c.H * 128, KVD = c.Hkv * 128;
-    if (layer >= c.L) {  // final norm + lm_head -> fp32 logits
-        ho.block = r; ho.dep = counter(c.L * 5 - 1); ho.expected = c.nb_down; ho.mine = nullptr;
-        DecodeGemvArgs g{};
-        g.W = c.lm_head; g.x = c.x; g.y32 = c.logits; g.N = c.V; g.K = c.D; g.norm_w = c.final_norm; g.norm_eps = c.eps;
-        gemv_body<1, CQ_UN, true, CQ_ROWS>(g, r, lds.g, ho);
-        return;
-    }
-    const DecodeLayerW& w = c.layers[layer];
-    const int op0 = layer * 5;
-    if (r < c.nb_qkv) {  // input_layernorm + q / k / v projections
-        ho.block = r; ho.dep = layer > 0 ? counter(op0 - 1) : nullptr; ho.expected = c.nb_down; ho.mine = counter(op0);
-        DecodeGemvArgs g{};
-        g.W = w.wq; g.Wb = w.wk; g.Wc = w.wv; g.x = c.x; g.y = c.q; g.yb = c.k; g.yc = c.v; g.N = HD; g.Nb = KVD; g.Nc = KVD; g.K = c.D;
-        g.norm_w = w.ln1; g.norm_eps = c.eps; g.bias = w.bq; g.bias_b = w.bk; g.bias_c = w.bv;
-        gemv_body<1, CQ_UN, true, CQ_ROWS>(g, r, lds.g, ho);
-        return;
-    }
-    r -= c.nb_qkv;
-    if (r < c.nb_attn) {  // rotary + cache update + split attention + merge
-        ho.block = r; ho.dep = counter(op0); ho.expected = c.nb_qkv; ho.mine = counter(op0 + 1);
-        DecodeAttnFusedArgs a{c.q, c.k, c.v, c.cos, c.sin, w.kc, w.vc, c.ao, c.attn_ws, c.pos, c.H, c.Hkv, 128, c.max_len, c.nsplit, c.scale};
-        attn_fused_body(a, r % c.H, r / c.H, lds.a, ho);
-        return;
-    }
-    r -= c.nb_attn;
-    if (r < c.nb_o) {  // x += o_proj(attention)
-        ho.block = r; ho.dep = counter(op0 + 1); ho.expected = c.nb_attn; ho.mine = counter(op0 + 2);
-        DecodeGemvArgs g{};
-        g.W = w.wo; g.x = c.ao; g.res = c.x; g.y = c.x; g.N = c.D; g.K = HD;
-        gemv_body<1, CO_UN, false, CO_ROWS>(g, r, lds.g, ho);
-        return;
-    }
-    r -= c.nb_o;
-    if (r < c.nb_gu) {  // post_attention_layernorm + silu(gate) * up
-        ho.block = r; ho.dep = counter(op0 + 2); ho.expected = c.nb_o; ho.mine = counter(op0 + 3);
-        DecodeGemvArgs g{};
-        g.W = w.wg; g.W2 = w.wu; g.x = c.x; g.y = c.mid; g.N = c.I; g.K = c.D; g.norm_w = w.ln2; g.norm_eps = c.eps;
-        gemv_body<2, CG_UN, true, CG_ROWS>(g, r, lds.g, ho);
-        return;
-    }
-    r -= c.nb_gu;
-    {   // x += down_proj(mid)
-        ho.block = r; ho.dep = counter(op0 + 3); ho.expected = c.nb_gu; ho.mine = counter(op0 + 4);
-        DecodeGemvArgs g{};
-        g.W = w.wd; g.x = c.mid; g.res = c.x; g.y = c.x; g.N = c.D; g.K = c.I;
-        gemv_body<1, CD_UN, false, CD_ROWS>(g, r, lds.g, ho);
-    }
-}
-
 }  // namespace
 
 hipError_t launch_decode_rmsnorm(const DecodeRmsArgs& a, hipStream_t s) {
@@ -1237,43 +939,6 @@ hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t 
     if (a.H <= 0 || a.nsplit <= 0 || a.N <= 0 || a.H * 256 > 64 * 1024) return hipErrorInvalidValue;  // x image in LDS: 256 B per head
     const int rows_per_block = OM_WAVES * OM_ROWS;
     hipLaunchKernelGGL(oproj_merge_kernel, dim3((a.N + rows_per_block - 1) / rows_per_block), dim3(OM_WAVES * 64), a.H * 256, s, a);
-    return hipGetLastError();
-}
-
-size_t decode_attn_oproj_counter_bytes() { return 2 * CHAIN_OP_STRIDE * sizeof(unsigned); }
-
-hipError_t launch_decode_attn_oproj(const DecodeAttnOprojArgs& a, hipStream_t s) {
-    const int K = a.a.H * 128, nblocks = a.a.H * a.a.nsplit;
-    if (a.a.hd != 128 || a.a.H <= 0 || a.a.Hkv <= 0 || a.a.H % a.a.Hkv != 0 || a.a.nsplit <= 0 || K % 512 != 0) return hipErrorInvalidValue;
-    if (a.D != nblocks * AO_ROWS) return hipErrorInvalidValue;  // one workgroup per (head, range) takes 16 rows: D = 16 H nsplit
-    const int lds = AO_ROWS * K * 2;
-    if (lds > 148 * 1024) return hipErrorInvalidValue;  // + 8.4 KB of static LDS (attention partials) <= 160 KB
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        if (hipError_t e = hipFuncSetAttribute((const void*)decode_attn_oproj_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); e != hipSuccess) return e;
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(decode_attn_oproj_kernel, dim3(nblocks), dim3(512), lds, s, a);
-    return hipGetLastError();
-}
-
-size_t decode_chain_counter_bytes(int layers) { return (size_t)(layers * 5 + 1) * CHAIN_OP_STRIDE * sizeof(unsigned); }
-
-// Every row count must fill whole blocks of its operation (GEMV_WAVES x rows-per-wave rows: CHAIN_CFG).
-hipError_t launch_decode_chain(const DecodeChainArgs& a_in, hipStream_t s) {
-    DecodeChainArgs a = a_in;
-    if (a.L <= 0 || a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
-    const int HD = a.H * 128, KVD = a.Hkv * 128;
-    const int rq = GEMV_WAVES * CQ_ROWS, ro = GEMV_WAVES * CO_ROWS, rg = GEMV_WAVES * CG_ROWS, rd = GEMV_WAVES * CD_ROWS;
-    if (HD % rq || KVD % rq || a.V % rq || a.D % ro || a.I % rg || a.D % rd || a.D % 8 || a.I % 8 || a.D < 512 || a.D > 8192 || a.I < 512)
-        return hipErrorInvalidValue;
-    a.nb_qkv = (HD + 2 * KVD) / rq; a.nb_attn = a.H * a.nsplit; a.nb_o = a.D / ro; a.nb_gu = a.I / rg; a.nb_down = a.D / rd;
-    a.nb_head = a.V / rq;
-    if (hipError_t e = hipMemsetAsync(a.counters, 0, decode_chain_counter_bytes(a.L), s); e != hipSuccess) return e;
-    const long blocks = (long)a.L * (a.nb_qkv + a.nb_attn + a.nb_o + a.nb_gu + a.nb_down) + a.nb_head;
-    hipLaunchKernelGGL(decode_chain_kernel, dim3((unsigned)blocks), dim3(DA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 

@@ -27,46 +27,22 @@
 #include <math.h>
 #include <type_traits>
 
-// Diagnostic builds only (tools/probes/gemm_stamps.hip defines MERV_GEMM_STAMPS before including this file): per-wave stamps of
-// the shader clock (s_memtime) and, at entry / exit, of the 100 MHz real-time counter plus the hardware ids of the CU, into a
-// buffer of their own. The product build compiles none of it.
-#ifdef MERV_GEMM_STAMPS
-__device__ unsigned long long* g_gemm_stamps = nullptr;  // [block][8 waves][16]
-#define MERV_GSTAMP_(k, INSTR)                                                                                       \
-    do {                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        unsigned long long t__;                                                                                      \
-        asm volatile(INSTR " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (g_gemm_stamps && (threadIdx.x & 63) == 0)                                                                \
-            g_gemm_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = t__;                         \
-    } while (0)
-#define MERV_GSTAMP(k) MERV_GSTAMP_(k, "s_memtime")
-#define MERV_GSTAMP_REAL(k) MERV_GSTAMP_(k, "s_memrealtime")
-#define MERV_GSTAMP_HWID(k)                                                                                          \
-    do {                                                                                                             \
-        if (g_gemm_stamps && (threadIdx.x & 63) == 0)                                                                \
-            g_gemm_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] =                               \
-                ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32) |    \
-                (unsigned)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));                        \
-    } while (0)
-#else
-#define MERV_GSTAMP(k) do { } while (0)
-#define MERV_GSTAMP_REAL(k) do { } while (0)
-#define MERV_GSTAMP_HWID(k) do { } while (0)
-#endif
-
-// Ablation builds only (tools/probes): MERV_ABL_NOSTORE keeps the whole epilogue but never stores (the condition is a runtime
-// value, so nothing is dead code); MERV_ABL_PLAINSTORE: direct epilogue with L2-allocating stores
-#ifdef MERV_ABL_WRAPROWS  // every output / residual row wraps into the first 4096 rows (8 MB at N = 1024: stays in the L2s)
-#define MERV_ABL_WRAP(r) ((r) & 4095)
-#else
-#define MERV_ABL_WRAP(r) (r)
-#endif
-#ifdef MERV_ABL_NOSTORE
-#define MERV_ABL_STORE_COND &&(p.group_m == 12345)
-#else
-#define MERV_ABL_STORE_COND
+// Probe hooks. The product build compiles every one of them to nothing / the identity; the diagnostic builds under tools/probes
+// (in-kernel stamps, ablations, operand-wrap energy probe) force-include tools/probes/gemm_probe_hooks.h, which defines
+// MERV_GEMM_PROBE_HOOKS and its own versions.
+#ifndef MERV_GEMM_PROBE_HOOKS
+#define MERV_GSTAMP(k) do { } while (0)          // s_memtime stamp k of this wave
+#define MERV_GSTAMP_REAL(k) do { } while (0)     // s_memrealtime stamp
+#define MERV_GSTAMP_HWID(k) do { } while (0)     // XCC_ID / HW_ID
+#define MERV_PROBE_OUT_ROW(r) (r)                // output / residual row an epilogue access goes to
+#define MERV_PROBE_A_ROW(r, p) (r)               // A row a DMA piece reads
+#define MERV_PROBE_W_ROW(r, p) (r)               // W row a DMA piece reads
+#define MERV_PROBE_STORE_COND(p) true            // ANDed into the store predicate
+#define MERV_PROBE_SKIP_W_DMA(t) false           // eight-phase kernel: drop the W pieces of K-tile t
+#define MERV_PROBE_NO_EPILOGUE 0                 // eight-phase kernel: prologue + K-loop only
+#define MERV_PROBE_DRAIN_STORES() do { } while (0)  // stamped builds wait for their stores before the last stamp
+#define MERV_PROBE_REST_MODE 0                   // launch_gemm: 0 remaining rows launched, 1 not computed, 2 an empty launch instead
+#define MERV_PROBE_REST_LAUNCH(s, e) (e)
 #endif
 
 namespace merv {
@@ -272,8 +248,8 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
                 if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
             }
-            c_off[it] = (uint32_t)MERV_ABL_WRAP(orow) * (uint32_t)p.ldc + wn0 + ec * 8;
-            r_off[it] = (uint32_t)MERV_ABL_WRAP(rr) * (uint32_t)p.ldres + wn0 + ec * 8;
+            c_off[it] = (uint32_t)MERV_PROBE_OUT_ROW(orow) * (uint32_t)p.ldc + wn0 + ec * 8;
+            r_off[it] = (uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + wn0 + ec * 8;
         }
         // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
         // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
@@ -325,11 +301,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         for (int it = 0; it < EP_IT; ++it) {
             const int r = (elane >> 3) + 8 * it;
             u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
-#ifdef MERV_ABL_RESNOUSE  // ablation: the residual rows are loaded but only consumed after the part's stores were issued
-            if (false) {
-#else
             if (p.res) {
-#endif
                 // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -365,14 +337,10 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                     *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
                     if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
                 }
-            } else if (valid[it] MERV_ABL_STORE_COND) {
+            } else if (valid[it] && MERV_PROBE_STORE_COND(p)) {
                 // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
                 // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
-#ifdef MERV_ABL_PLAINSTORE
-                *(u32x4*)(p.C + (size_t)c_off[it]) = t;
-#else
                 __builtin_nontemporal_store(t, (u32x4*)(p.C + (size_t)c_off[it]));
-#endif
             }
         }
         if (p.stats_out) {
@@ -384,10 +352,6 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             if (elane < 8 * EP_IT && m < p.M)
                 *(float2*)(p.stats_out + 2 * ((size_t)(wn0 >> 6) * p.stats_ld + m)) = float2{sm, m2};
         }
-#ifdef MERV_ABL_RESNOUSE
-#pragma unroll
-        for (int it = 0; it < EP_IT; ++it) asm volatile("" ::"v"(resv[it]));
-#endif
     }
 }
 
@@ -462,8 +426,8 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                 if (p.out_group > 0) orow = (mc / p.out_group) * p.out_stride + p.out_off + (mc % p.out_group);
                 if (p.res_row_mod > 0) rr = mc % p.res_row_mod;
             }
-            c_off[j] = (uint32_t)MERV_ABL_WRAP(orow) * (uint32_t)p.ldc + nl;
-            r_off[j] = (uint32_t)MERV_ABL_WRAP(rr) * (uint32_t)p.ldres + nl;
+            c_off[j] = (uint32_t)MERV_PROBE_OUT_ROW(orow) * (uint32_t)p.ldc + nl;
+            r_off[j] = (uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + nl;
         }
         // one wave-uniform branch around ALL residual loads
         if (p.res) {
@@ -539,15 +503,10 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                         if (fq == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)(ex + 127);
                     }
                 }
-            } else if (valid[j] MERV_ABL_STORE_COND) {
+            } else if (valid[j] && MERV_PROBE_STORE_COND(p)) {
                 // streaming stores (no L2 allocation: see gemm_epilogue)
-#ifdef MERV_ABL_PLAINSTORE
-                *(u32x4*)(p.C + (size_t)c_off[j]) = t[0];
-                *(u32x4*)(p.C + (size_t)c_off[j] + 32) = t[1];
-#else
                 __builtin_nontemporal_store(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
                 __builtin_nontemporal_store(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
-#endif
             }
         }
         if (p.stats_out) {  // one store of 16 MI consecutive float2 per part (layout [N / 64][M][2])
@@ -827,10 +786,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int u = 0; u < 2; ++u) {
             int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
             grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
+            grow = MERV_PROBE_A_ROW(grow, p);
             a_src[sq][u] = (const char*)p.A + (size_t)grow * p.lda * ES + sw8;
             // LDS row slot ((wave >> 2) + 2 u) * 64 + sq * 32 + (wave & 3) * 8 + r8; DIRECT: it receives the permuted W row
             const int s32 = (wave & 3) * 8 + r8;
-            const int nrow = n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32);
+            const int nrow = MERV_PROBE_W_ROW(n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32), p);
             b_src[sq][u] = (const char*)p.W + (size_t)nrow * p.ldw * ES + sw8;
         }
     auto dma = [&](const char* src, int lds_off) {
@@ -842,9 +802,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
-#ifdef MERV_ABL_HALFDMA  // ablation: W tiles after K-tile 0 are never loaded (garbage results; is the K-loop load-path-bound?)
-        if (t > 0) return;
-#endif
+        if (MERV_PROBE_SKIP_W_DMA(t)) return;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             dma(b_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
@@ -1065,19 +1023,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     if (wr == 0) asm volatile("s_barrier" ::: "memory");  // balance the trailing group's extra barrier
     MERV_GSTAMP(4);  // K-loop done
 
-#ifdef MERV_ABL_NOEPI  // ablation: prologue + K-loop + block turnover only
+    if constexpr (MERV_PROBE_NO_EPILOGUE) {
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
-#else
-    if constexpr (DIRECT) gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
-    else gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
-#endif
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (DIRECT) {
+        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
+    } else {
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+    }
     MERV_GSTAMP(10);  // part 1's stores are issued
-#ifdef MERV_GEMM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    MERV_PROBE_DRAIN_STORES();
     MERV_GSTAMP(11);  // every store acknowledged
     MERV_GSTAMP_REAL(12);
 }
@@ -1170,9 +1127,6 @@ hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     }
 }
 
-#ifdef MERV_ABL_REST
-__global__ void noop_kernel() {}
-#endif
 int g_gemm_variant = 0;
 int g_gemm_group_m = 0;  // 0 auto, 1: 128x128, 2: 256x256, 3: 256x128
 
@@ -1246,6 +1200,14 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
     }
 }
 
+// GemmArgs::row_add (the next block's temporal embedding, added by fc2) exists in the LDS epilogue only: refused for launches that
+// would take the direct one (activation launches; every launch of a -DMERV_GEMM_EPILOGUE=1 A/B build)
+inline bool row_add_ok(const GemmArgs& a) {
+    if (!a.row_add) return true;
+    if (a.act != ACT_NONE || gemm_direct_epilogue<ACT_NONE>) return false;
+    return a.row_add_div >= 256 && a.row_add_mod > 0 && a.out_group <= 0 && !a.mx_out_q;
+}
+
 }  // namespace
 
 void set_gemm_variant(int v) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
@@ -1259,7 +1221,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 8 != 0) return hipErrorInvalidValue;
-    if (a.row_add && (a.act != ACT_NONE || a.row_add_div < 256 || a.row_add_mod <= 0 || a.out_group > 0 || a.mx_out_q)) return hipErrorInvalidValue;
+    if (!row_add_ok(a)) return hipErrorInvalidValue;
     {   // the epilogue keeps element offsets in 32 bits
         const double rows_out = a.out_group > 0 ? ((double)(a.M / a.out_group) + 1) * a.out_stride + a.out_off : (double)a.M;
         if (rows_out * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
@@ -1283,13 +1245,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     top.M = rows1;
     hipError_t e = dispatch(top, true);
     if (e != hipSuccess || rows1 == a.M) return e;
-#ifdef MERV_ABL_REST  // ablation builds (wrong results): 1 = the remaining rows are not computed at all, 2 = an empty launch in their place
-    if (MERV_ABL_REST == 1) return e;
-    if (MERV_ABL_REST == 2) {
-        hipLaunchKernelGGL(noop_kernel, dim3(1), dim3(64), 0, s);
-        return hipGetLastError();
-    }
-#endif
+    if constexpr (MERV_PROBE_REST_MODE != 0) return MERV_PROBE_REST_LAUNCH(s, e);
     GemmArgs rest = a;  // independent rows: same stream, no ordering requirement between the two launches
     rest.M = a.M - rows1;
     rest.A = a.A + (size_t)rows1 * a.lda;
@@ -1307,8 +1263,11 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 
 // MXFP8 GEMM (A, W: OCP e4m3 bytes, row-major, K contiguous; block scales in the layout mx_quantize writes).
 // Requirements: K % 256 == 0 and K >= 512 (an even number >= 4 of 128-element K-tiles), N % 256 == 0, no row remapping.
-hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 0) return hipSuccess;
+hipError_t launch_gemm_mx(const GemmArgs& a_in, hipStream_t s) {
+    if (a_in.M <= 0) return hipSuccess;
+    GemmArgs a = a_in;
+    if (a.stats_out && a.stats_ld <= 0) a.stats_ld = a.M;  // as launch_gemm: rows of the partials array [N / 64][stats_ld][2]
+    if (!row_add_ok(a)) return hipErrorInvalidValue;
     if (!a.mx_scale_a || !a.mx_scale_w || a.mx_groups_a < (a.M + 63) / 64 || a.mx_groups_w < a.N / 64) return hipErrorInvalidValue;
     if (a.K % 256 != 0 || a.K < 512 || a.N % 256 != 0 || a.out_group > 0 || a.res_row_mod > 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw) % 16 != 0 || a.ldc % 8 != 0 || (a.res && a.ldres % 8 != 0)) return hipErrorInvalidValue;

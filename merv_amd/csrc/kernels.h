@@ -420,42 +420,4 @@ hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t 
 // greedy decoding inside a captured step: tok[0] <- argmax(logits[V]) (first maximum), out_tokens[*pos - pos0] <- it, *pos += 1
 hipError_t launch_decode_greedy_advance(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s);
 
-// merv_decode_attention_fused + the o-projection with its residual (x += W_o . attention) as ONE launch: the workgroups' loader
-// waves bring W_o into LDS while the attention runs (decode.hip, decode_attn_oproj_kernel). Requires D == 16 * H * nsplit.
-struct DecodeAttnOprojArgs {
-    DecodeAttnFusedArgs a;   // a.out: the attention output [H * hd] (still written: the o-projection's input)
-    const bf16_t* Wo;        // [D, H * hd]
-    bf16_t* x;               // [D] residual stream, updated in place
-    int D;
-    unsigned* counters;      // decode_attn_oproj_counter_bytes() bytes per layer, zeroed once per generation
-    unsigned* err;           // one word, OR-ed when a wait gives up
-};
-size_t decode_attn_oproj_counter_bytes();
-hipError_t launch_decode_attn_oproj(const DecodeAttnOprojArgs& a, hipStream_t s);
-
-// The whole batch-1 decode step (all layers + lm_head) as ONE launch: decode.hip, decode_chain_kernel.
-struct DecodeLayerW {  // device table, one entry per layer
-    const bf16_t *wq, *wk, *wv, *wo, *wg, *wu, *wd;  // nn.Linear weights [out, in]
-    const bf16_t *ln1, *ln2;                         // input_layernorm / post_attention_layernorm weights
-    const bf16_t *bq, *bk, *bv;                      // q / k / v biases or nullptr
-    bf16_t *kc, *vc;                                 // this layer's caches [Hkv, max_len, 128]
-};
-struct DecodeChainArgs {
-    const DecodeLayerW* layers;  // device memory, [L]
-    int L, D, I, H, Hkv, hd, V, max_len, nsplit;
-    bf16_t *x, *q, *k, *v, *ao, *mid;  // activations [D], [H hd], [Hkv hd] x 2, [H hd], [I]; x holds the token's embedding on entry
-    float* logits;                     // [V] fp32
-    const bf16_t *cos, *sin;           // [max_len, hd]
-    const long* pos;                   // device int64
-    float* attn_ws;                    // merv_decode_attention_fused_workspace_floats(H, nsplit)
-    const bf16_t* final_norm;          // [D]
-    const bf16_t* lm_head;             // [V, D]
-    unsigned* counters;                // decode_chain_counter_bytes(L) bytes, zeroed by the launcher
-    unsigned* err;                     // one word, never cleared by the library: non-zero = a wait gave up
-    float eps, scale;
-    int nb_qkv, nb_attn, nb_o, nb_gu, nb_down, nb_head;  // filled by the launcher
-};
-size_t decode_chain_counter_bytes(int layers);
-hipError_t launch_decode_chain(const DecodeChainArgs& a, hipStream_t s);
-
 }  // namespace merv

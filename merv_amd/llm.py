@@ -187,9 +187,10 @@ class LlamaBackbone:
                 and (eos_token_id is None or min_new_tokens == 0) and dec.use_greedy_graph):
             # greedy search entirely on the device: every replayed step picks its own successor (HipDecoder.greedy_run)
             first = logits.argmax(-1)
+            if max_new_tokens == 1 or (eos_token_id is not None and int(first) == eos_token_id):
+                return first[None]  # nothing to decode: no step runs, no graph is captured
             rest = dec.greedy_run(first, max_new_tokens - 1, inputs_embeds.shape[1], eos_token_id)
             ids = torch.cat([first, rest])[None]
-            dec.check_chain()
             if eos_token_id is not None:
                 hit = (ids[0] == eos_token_id).nonzero()
                 if hit.numel():
@@ -227,8 +228,6 @@ class LlamaBackbone:
             if i + 1 < max_new_tokens:
                 logits = step(nxt)
         ids = torch.stack(new_tokens, 1)
-        if hasattr(dec, "check_chain"):
-            dec.check_chain()  # the one-launch decode step reports a stuck hand-off instead of hanging: fail loudly
         if eos_token_id is not None:  # the EOS test above runs every 8 tokens: cut at the step where every row had finished
             all_done = ((ids == eos_token_id).cumsum(1) > 0).all(0)
             if bool(all_done.any()):
@@ -275,6 +274,9 @@ class StaticDecoder:
         self.K = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
         self.V = [torch.zeros(batch, self.Hkv, max_len, self.hd, dtype=self.dt, device=self.dev) for _ in range(L)]
         self.ar = torch.arange(max_len, device=self.dev)
+        # the token a step embeds: ONE tensor for the decoder's life. Every captured graph (decode(), HipDecoder.greedy_run) reads and
+        # writes THIS storage; callers only ever copy_ into it (rebinding it after a capture would leave that graph on freed memory).
+        self.tok = torch.zeros(batch, 1, dtype=torch.long, device=self.dev)
         self.graph = None
 
     def _rms(self, x, w):
@@ -336,8 +338,8 @@ class StaticDecoder:
     @torch.inference_mode()
     def decode(self, token: torch.Tensor, use_graph: bool = True) -> torch.Tensor:
         """token [B] (the token at position self.pos) -> logits for the next position [B, vocab] (fp32)."""
+        self.tok.copy_(token[:, None])
         if self.graph is None:
-            self.tok = token[:, None].clone()
             if not use_graph:
                 out = self._step()
                 self.pos += 1
@@ -347,8 +349,6 @@ class StaticDecoder:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.logits = self._step()
-        else:
-            self.tok.copy_(token[:, None])
         if use_graph:
             self.graph.replay()
             self.pos += 1
@@ -392,70 +392,25 @@ class HipDecoder(StaticDecoder):
         self.ws = torch.zeros(max(self.lib.merv_decode_attention_fused_workspace_floats(self.H, self.NSPLIT),
                                   self.lib.merv_decode_attention_split_workspace_floats(self.H, self.NSPLIT)), dtype=torch.float32, device=self.dev)
         self.logits32 = torch.empty(1, cfg.vocab_size, dtype=torch.float32, device=self.dev)
-        self.chain = None  # built at the first step (the position tensor it points to is created by prefill())
-        self._want_chain = self.use_chain and self.chain_supported(hf_model)
-        # attention + o-projection as one launch (W_o rides into LDS under the attention chain): needs D == 16 * H * NSPLIT
-        self.fuse_ao = (self.use_attn_oproj and D == 16 * self.H * self.NSPLIT and (self.H * self.hd) % 512 == 0 and self.H * self.hd <= 4608)
-        nlay = cfg.num_hidden_layers
-        self.ao_stride = self.lib.merv_decode_attn_oproj_counter_bytes() // 4
-        self.ao_counters = torch.zeros(nlay * self.ao_stride, dtype=torch.int32, device=self.dev)
-        self.chain_err = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # greedy_run's token log (token chosen AT position p, for p + 1): one tensor for the decoder's life, like self.tok
+        self.out_tokens = torch.zeros(max_len, dtype=torch.long, device=self.dev)
+        if self.use_hip_prefill and self.fuse_qkv:
+            for lyr in hf_model.model.layers:  # re-homes q / k / v of every layer once, here (see _qkv_fused)
+                self._qkv_fused(lyr.self_attn)
 
-    # The whole step as ONE launch (csrc/decode.hip, decode_chain_kernel): bit-identical but measured slower than the launches
-    # (EXPERIMENTS.md section 5) -- opt-in, MERV_DECODE_CHAIN=1
-    use_chain = os.environ.get("MERV_DECODE_CHAIN", "0") == "1"
-    # attention + o-projection as one launch: bit-identical, measured 2.4 us per layer SLOWER than the two launches -- opt-in too
-    use_attn_oproj = os.environ.get("MERV_DECODE_ATTN_OPROJ", "0") == "1"
     # the attention launch ends at its split partials and the o-projection merges them under its first weight trip (bit-identical to
-    # the fused attention launch + the plain o-projection; 4.8 us per layer faster): default; MERV_DECODE_SPLIT_MERGE=0 restores them
+    # the fused attention launch + the plain o-projection; 4.8 us per layer faster): default; MERV_DECODE_SPLIT_MERGE=0 restores them.
+    # (Round 4 also built attention + o-projection and the whole step as ONE launch; both bit-identical and slower, removed in round 5:
+    # git 05f38ce / 0dad582, EXPERIMENTS.md section 5.)
     use_split_merge = os.environ.get("MERV_DECODE_SPLIT_MERGE", "1") != "0"
     # greedy generation with the argmax / token hand-over / position increment inside the captured step; MERV_DECODE_GREEDY_GRAPH=0: host loop
     use_greedy_graph = os.environ.get("MERV_DECODE_GREEDY_GRAPH", "1") != "0"
-
-    @staticmethod
-    def chain_supported(hf_model) -> bool:
-        cfg = hf_model.config
-        hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
-        kvd = getattr(cfg, "num_key_value_heads", cfg.num_attention_heads) * hd
-        return (hd == 128 and cfg.hidden_size % 8 == 0 and 512 <= cfg.hidden_size <= 8192 and cfg.intermediate_size % 8 == 0 and
-                cfg.intermediate_size >= 512 and cfg.vocab_size % 8 == 0 and kvd % 8 == 0)
-
-    def _build_chain(self):
-        from ._lib import DECODE_LAYER_FIELDS, DecodeChain, ptr
-        m, cfg = self.m, self.cfg
-        rows = []
-        for li, lyr in enumerate(m.model.layers):
-            a, mlp = lyr.self_attn, lyr.mlp
-            bias = lambda lin: 0 if lin.bias is None else ptr(lin.bias)
-            e = dict(wq=ptr(a.q_proj.weight), wk=ptr(a.k_proj.weight), wv=ptr(a.v_proj.weight), wo=ptr(a.o_proj.weight),
-                     wg=ptr(mlp.gate_proj.weight), wu=ptr(mlp.up_proj.weight), wd=ptr(mlp.down_proj.weight),
-                     ln1=ptr(lyr.input_layernorm.weight), ln2=ptr(lyr.post_attention_layernorm.weight),
-                     bq=bias(a.q_proj), bk=bias(a.k_proj), bv=bias(a.v_proj), k_cache=ptr(self.K[li]), v_cache=ptr(self.V[li]))
-            rows.append([e[f] for f in DECODE_LAYER_FIELDS])
-        self._chain_layers = torch.tensor(rows, dtype=torch.int64, device=self.dev)  # the device table of merv_decode_layer entries
-        self._chain_counters = torch.zeros(self.lib.merv_decode_chain_counter_bytes(len(rows)) // 4, dtype=torch.int32, device=self.dev)
-        c = DecodeChain()
-        c.layers = ptr(self._chain_layers)
-        c.L, c.D, c.I, c.H, c.Hkv, c.hd, c.V = len(rows), cfg.hidden_size, cfg.intermediate_size, self.H, self.Hkv, self.hd, cfg.vocab_size
-        c.max_len, c.nsplit = self.max_len, self.NSPLIT
-        c.x, c.q, c.k, c.v, c.ao, c.mid = ptr(self.x), ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.ao), ptr(self.mid)
-        c.logits, c.cos_t, c.sin_t, c.pos, c.attn_ws = ptr(self.logits32), ptr(self.cos), ptr(self.sin), ptr(self.pos), ptr(self.ws)
-        c.final_norm, c.lm_head = ptr(m.model.norm.weight), ptr(m.lm_head.weight)
-        c.counters, c.err = ptr(self._chain_counters), ptr(self.chain_err)
-        c.eps, c.scale = self.eps, self.hd**-0.5
-        return c
-
-    def check_chain(self) -> None:
-        """Raises if a wait inside a chained step ever gave up (one host read; generate() calls it once per generation)."""
-        if int(self.chain_err.item()) != 0:
-            raise RuntimeError("HIP decode step: an in-launch hand-off wait timed out (results invalid)")
 
     def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         # the fused attention launch expects its per-head arrival counters at zero and restores them itself; an aborted launch
         # (a fault, a killed process sharing the buffer) would leave them non-zero and every later merge would misfire -- so every
         # generation starts from a zeroed workspace (one memset per generate(), nothing per token)
         self.ws.zero_()
-        self.ao_counters.zero_()  # the fused attention + o-projection launches restore their counters; an aborted one would not
         if not self.use_hip_prefill:
             return super().prefill(inputs_embeds)
         return self._prefill_fused(inputs_embeds)
@@ -467,12 +422,24 @@ class HipDecoder(StaticDecoder):
     # ... and the causal attention on merv_prefill_attention (head dim 128) instead of PyTorch-ROCm's SDPA; MERV_HIP_PREFILL_ATTN=0: SDPA
     use_hip_prefill_attn = os.environ.get("MERV_HIP_PREFILL_ATTN", "1") != "0"
 
+    # q / k / v of the prompt as one library GEMM (below); MERV_PREFILL_FUSE_QKV=0 keeps the module's three parameters untouched
+    fuse_qkv = os.environ.get("MERV_PREFILL_FUSE_QKV", "1") != "0"
+
     def _qkv_fused(self, attn):
         """The q / k / v projection weights (and biases) of one attention module as ONE [Nq + Nk + Nv, D] matrix, so the prompt's
         three projections are one library GEMM (105 us against 3 x 45 at 1049 tokens). No second copy: the three parameters are
         re-homed as row ranges of the fused tensor (`param.data = fused[a:b]`, same values, contiguous rows -- what the decode
-        kernels read through their own pointers), so in-place loads keep updating it; a parameter whose storage was replaced since
-        is detected by its address and the layer is fused again."""
+        kernels read through their own pointers), so in-place loads keep updating it.
+
+        THIS MUTATES THE HF MODULE, once, when the decoder is built (not as a side effect of a later generate()): afterwards the
+        three parameters of a layer share one storage. `state_dict()` / `load_state_dict()` / in-place optimiser updates are
+        unaffected (each parameter is still its own contiguous row range); what notices is code that checks for shared storage --
+        `safetensors.torch.save_file` / `save_pretrained(safe_serialization=True)` refuse aliasing tensors: clone the state dict
+        first, or build the decoder with MERV_PREFILL_FUSE_QKV=0 ("LLM hand-off"). A parameter whose storage was
+        REPLACED since (`param.data = ...`, `load_state_dict(assign=True)`) is detected by its address at the next prefill: the layer
+        is fused again and every captured decode graph is dropped, because the graphs hold the old weight pointers."""
+        if not self.fuse_qkv:
+            return None
         projs = (attn.q_proj, attn.k_proj, attn.v_proj)
         fused = getattr(attn, "_merv_qkv", None)
         ok = fused is not None
@@ -498,6 +465,9 @@ class HipDecoder(StaticDecoder):
                 if has_b:
                     pr.bias.data = b[off:off + n]
                 off += n
+            if fused is not None:  # a re-fuse: the captured steps read the storage the parameters had before
+                self.graph = None
+                self.greedy_graph = self.greedy_graph_chunk = None
             fused = attn._merv_qkv = (w, b)
         return fused
 
@@ -573,7 +543,7 @@ class HipDecoder(StaticDecoder):
 
     # Greedy decoding with nothing but the graph replay per token: the captured step ends with merv_decode_greedy_advance (argmax ->
     # next token, token log, position + 1, all on the device) instead of the host loop's argmax / copy / add kernels (23 us per token).
-    greedy_graph = None
+    greedy_graph = greedy_graph_chunk = None
     GREEDY_CHUNK = 8
 
     @torch.inference_mode()
@@ -584,9 +554,8 @@ class HipDecoder(StaticDecoder):
         from ._lib import check, ptr
         if steps <= 0:
             return torch.empty(0, dtype=torch.long, device=self.dev)
+        self.tok.copy_(token[:, None])  # (never rebound: decode()'s graph and these graphs embed from the same tensor)
         if self.greedy_graph is None:
-            self.tok = token[:, None].clone()
-            self.out_tokens = torch.zeros(self.max_len, dtype=torch.long, device=self.dev)  # token chosen AT position p (for p + 1)
             self._step()  # warm-up outside the capture; the advance is not run: it would move the position
             torch.cuda.synchronize(self.dev)
 
@@ -603,8 +572,6 @@ class HipDecoder(StaticDecoder):
             # three small kernels per token had been hiding in that gap), a chunk pays it once
             self.greedy_graph = capture(1)
             self.greedy_graph_chunk = capture(self.GREEDY_CHUNK)
-        else:
-            self.tok.copy_(token[:, None])
         done = 0
         while done < steps:
             if steps - done >= self.GREEDY_CHUNK:
@@ -625,12 +592,6 @@ class HipDecoder(StaticDecoder):
             st = torch.cuda.current_stream(self.dev).cuda_stream
             D, I, H, Hkv, hd = self.cfg.hidden_size, self.cfg.intermediate_size, self.H, self.Hkv, self.hd
             self.x.copy_(m.model.embed_tokens(self.tok).reshape(-1))
-            if self._want_chain and self.chain is None:
-                self.chain = self._build_chain()
-            if self.chain is not None:
-                import ctypes
-                check(lib.merv_decode_chain_step(ctypes.addressof(self.chain), st), "merv_decode_chain_step")
-                return self.logits32
             x, h, pos = ptr(self.x), ptr(self.h), ptr(self.pos)
 
             def gemv(W, W2, xin, res, y, N, K, y32=0, norm=None):
@@ -645,12 +606,7 @@ class HipDecoder(StaticDecoder):
                                                  ptr(self.v), H * hd, Hkv * hd, Hkv * hd, D, ptr(lyr.input_layernorm.weight), self.eps,
                                                  0 if bq is None else ptr(bq), 0 if bk is None else ptr(bk), 0 if bv is None else ptr(bv), st),
                       "merv_decode_gemv3_bias")
-                if self.fuse_ao:  # rotary + cache + attention + merge + (x += o_proj(attn)): one launch
-                    check(lib.merv_decode_attn_oproj(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
-                                                     ptr(self.V[li]), ptr(self.ao), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5,
-                                                     ptr(a.o_proj.weight), x, D, ptr(self.ao_counters) + 4 * li * self.ao_stride,
-                                                     ptr(self.chain_err), st), "merv_decode_attn_oproj")
-                elif self.use_split_merge and H <= 256:
+                if self.use_split_merge and H <= 256:
                     # rotary + cache + split attention; then x += o_proj(merge of the splits): the merge rides under the weight loads
                     check(lib.merv_decode_attention_split(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
                                                           ptr(self.V[li]), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5, st),

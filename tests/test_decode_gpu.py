@@ -178,49 +178,6 @@ def test_fused_attention_launch_equals_the_three_kernels(dev, H, Hkv, pos):
     assert rel_l2(out_c, ref) < 6e-3 and rel_l2(out_c, out_a) < 6e-3
 
 
-@pytest.mark.parametrize("H,Hkv,pos", [(32, 32, 1048), (32, 8, 1049), (32, 32, 0), (8, 8, 301), (4, 1, 16)])
-def test_attention_oproj_launch_equals_the_two_launches(dev, H, Hkv, pos):
-    """merv_decode_attn_oproj (the o-projection's 16 rows per workgroup brought into LDS by loader waves while the attention runs,
-    the attention output handed over inside the launch) gives the bits of merv_decode_attention_fused followed by merv_decode_gemv
-    with the residual, over consecutive positions AND a repeated one on the same counters (every launch restores them, as a
-    replayed graph needs) and leaves the same cache behind; the wait-timeout word stays zero."""
-    from merv_amd import _lib
-    from merv_amd._lib import check, ptr
-    lib = _lib.load()
-    hd, max_len, ns = 128, 1280, 8
-    D = 16 * H * ns
-    g = torch.Generator().manual_seed(H * 77 + pos)
-    bf = lambda t: t.to(torch.bfloat16).to(dev)
-    Kc, Vc = bf(torch.randn(Hkv, max_len, hd, generator=g)), bf(torch.randn(Hkv, max_len, hd, generator=g))
-    Wo = bf(torch.randn(D, H * hd, generator=g) * (H * hd) ** -0.5)
-    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-    emb = torch.outer(torch.arange(max_len, dtype=torch.float32), inv)
-    emb = torch.cat([emb, emb], -1)
-    cos, sin = bf(emb.cos()), bf(emb.sin())
-    ws_a = torch.zeros(lib.merv_decode_attention_fused_workspace_floats(H, ns), dtype=torch.float32, device=dev)
-    ws_b = torch.zeros_like(ws_a)
-    counters = torch.zeros(lib.merv_decode_attn_oproj_counter_bytes() // 4, dtype=torch.int32, device=dev)
-    err = torch.zeros(1, dtype=torch.int32, device=dev)
-    Ka, Va, Kb, Vb = Kc.clone(), Vc.clone(), Kc.clone(), Vc.clone()
-    for step in (0, 1, 1, 2):
-        p = torch.tensor([pos + step], dtype=torch.int64, device=dev)
-        q, k, v = bf(torch.randn(H * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g)), bf(torch.randn(Hkv * hd, generator=g))
-        x = bf(torch.randn(D, generator=g))
-        ao_a, x_a = torch.empty(H * hd, dtype=torch.bfloat16, device=dev), x.clone()
-        check(lib.merv_decode_attention_fused(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Ka), ptr(Va), ptr(ao_a), ptr(ws_a),
-                                              H, Hkv, hd, max_len, ns, hd**-0.5, _st(dev)), "fused")
-        check(lib.merv_decode_gemv(ptr(Wo), 0, ptr(ao_a), ptr(x_a), ptr(x_a), 0, D, H * hd, 0, 1e-5, _st(dev)), "o_proj")
-        ao_b, x_b = torch.full_like(ao_a, float("nan")), x.clone()
-        check(lib.merv_decode_attn_oproj(ptr(q), ptr(k), ptr(v), ptr(cos), ptr(sin), ptr(p), ptr(Kb), ptr(Vb), ptr(ao_b), ptr(ws_b), H, Hkv, hd,
-                                         max_len, ns, hd**-0.5, ptr(Wo), ptr(x_b), D, ptr(counters), ptr(err), _st(dev)), "attn_oproj")
-        torch.cuda.synchronize()
-        assert int(err.item()) == 0
-        assert torch.equal(ao_b, ao_a), step
-        assert torch.equal(x_b, x_a), (step, float((x_b.float() - x_a.float()).abs().max()))
-        assert torch.equal(Kb, Ka) and torch.equal(Vb, Va)
-        assert int(counters.abs().sum()) == 0  # restored
-
-
 @pytest.mark.parametrize("kv_heads,family", [(2, "llama"), (1, "mistral"), (1, "llama3.1"), (1, "qwen2")])
 def test_hip_decoder_matches_pytorch_decoder(dev, kv_heads, family):
     """Same random model, same prefill (PyTorch-ROCm, as the north_star keeps it), then token-by-token decode on both decoders,
@@ -548,6 +505,40 @@ def test_greedy_generation_on_the_device_equals_the_host_loop(dev, eos):
     assert torch.equal(out, ref) and torch.equal(out2, ref)
     if eos:
         assert int(out[0, -1]) == eos_id and out.shape[1] <= 11
+
+
+def test_one_decoder_alternating_greedy_and_sampled_generations(dev):
+    """ONE HipDecoder serving greedy (device-side greedy_run graphs) and non-greedy (decode() graph) generations in turn, both orders:
+    the two sets of captured graphs embed from the same token tensor, which is never rebound (a rebound tensor left the
+    other path's graph reading freed memory). Greedy results must equal those of a fresh decoder; sampled ones must equal the same
+    seeded call on a fresh decoder; a first token that already is the EOS returns at once."""
+    from merv_amd.llm import HipDecoder, LlamaBackbone
+    llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                             num_key_value_heads=2, max_position_embeddings=2048, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
+    emb = (torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(11)) * 0.5).to(torch.bfloat16).to(dev)
+    gen = lambda seed: torch.Generator(device=dev).manual_seed(seed)
+    sample = lambda: llm.generate_from_embeds(emb, max_new_tokens=19, do_sample=True, temperature=0.9, top_k=40, generator=gen(5))
+    penal = lambda: llm.generate_from_embeds(emb, max_new_tokens=19, repetition_penalty=1.3)
+    greedy = lambda: llm.generate_from_embeds(emb, max_new_tokens=19)
+    ref = {}
+    for name, fn in (("greedy", greedy), ("sample", sample), ("penal", penal)):  # each on a fresh decoder
+        llm._decoders.clear()
+        ref[name] = fn()
+    for order in (("greedy", "sample", "greedy", "penal", "greedy", "sample"), ("sample", "greedy", "penal", "greedy")):
+        llm._decoders.clear()
+        fns = {"greedy": greedy, "sample": sample, "penal": penal}
+        dec0 = None
+        for i, name in enumerate(order):
+            out = fns[name]()
+            dec = next(iter(llm._decoders.values()))
+            assert isinstance(dec, HipDecoder) and (dec0 is None or dec is dec0)  # one decoder throughout
+            dec0 = dec
+            assert torch.equal(out, ref[name]), (order, i, name, out.tolist(), ref[name].tolist())
+        assert dec0.tok.data_ptr() == dec.tok.data_ptr() and dec0.graph is not None and dec0.greedy_graph is not None
+    first = int(ref["greedy"][0, 0])
+    only = llm.generate_from_embeds(emb, max_new_tokens=19, eos_token_id=first)
+    assert only.tolist() == [[first]]
+    assert llm.generate_from_embeds(emb, max_new_tokens=1).tolist() == [[first]]
 
 
 def test_generate_uses_hip_decoder_when_it_can(dev):

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libmerv_hip.so does not export {n}"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.merv_abi_version() == 2
+    assert lib.merv_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

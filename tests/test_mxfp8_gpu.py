@@ -106,3 +106,25 @@ def test_encoder_mxfp8_mode_vs_emulating_oracle(dev, name):
     assert rel_l2(ref_bf16, ref) < 2e-2  # the default path is untouched
     cost = rel_l2(out, ref)
     assert 5e-3 < cost < 0.15, cost
+
+
+@pytest.mark.parametrize("name,gemms", [("siglip", ("fc2",)), ("siglip", ("proj", "fc2")), ("languagebind", ("proj", "fc2")), ("siglip", ("qkv", "fc1"))])
+def test_partial_mxfp8_mask_with_folded_layernorm(dev, name, gemms):
+    """A partial MXFP8 mask under the LayerNorm fold: with proj / fc2 on MXFP8 operands THEIR epilogues write the row
+    statistics partials the folded bf16 qkv / fc1 consume ([N / 64][stats_ld][2]: launch_gemm_mx has to default stats_ld like
+    launch_gemm, or every column tile lands on the same M rows), and with qkv / fc1 on MXFP8 the bf16 producers feed the MX
+    consumers. Checked against the same mask with separate LayerNorm kernels (same quantised GEMMs, no fold): the two must agree to
+    the fold's own tolerance, which stale statistics miss by orders of magnitude."""
+    import dataclasses
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    spec = next(s for s in merv_full_specs() if s.name == name)
+    spec = dataclasses.replace(spec, layers=3, frames=8 if name == "languagebind" else 4)
+    W = random_weights(spec, seed=13)
+    pix = torch.randn(spec.pixel_shape(2), generator=torch.Generator().manual_seed(4)).to(dev)
+    fold = HipEncoder(spec, W, dev, ln_fold=True).enable_mxfp8(gemms)
+    plain = HipEncoder(spec, W, dev, ln_fold=False).enable_mxfp8(gemms)
+    a, b = fold.forward(pix).float().cpu(), plain.forward(pix).float().cpu()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    # two roundings of the same function (e4m3 flips on near-ties included): a few percent; wrong statistics give O(1)
+    assert rel_l2(a, b) < 6e-2, rel_l2(a, b)

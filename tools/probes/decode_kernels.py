@@ -70,17 +70,12 @@ def main():
             d.NSPLIT, hd**-0.5, st), "split"),
         "o_proj merging the splits + residual": lambda l, li, st: check(lib.merv_decode_oproj_merge(
             ptr(l.self_attn.o_proj.weight), x, ptr(scratch), ptr(d.ws), 0, D, H, hd, d.NSPLIT, st), "om"),
-        "attention + o_proj, one launch": lambda l, li, st: check(lib.merv_decode_attn_oproj(
-            ptr(d.q), ptr(d.k), ptr(d.v), ptr(d.cos), ptr(d.sin), pos, ptr(d.K[li]), ptr(d.V[li]), ptr(d.ao), ptr(d.ws), H, Hkv, hd, d.max_len,
-            d.NSPLIT, hd**-0.5, ptr(l.self_attn.o_proj.weight), ptr(scratch), D, ptr(d.ao_counters) + 4 * li * d.ao_stride, ptr(d.chain_err), st), "ao"),
         "gate / up (norm, silu*up fused)": lambda l, li, st: gemv(l.mlp.gate_proj.weight, l.mlp.up_proj.weight, x, 0, ptr(d.mid), I, D, st,
                                                                    norm=l.post_attention_layernorm.weight),
         "down_proj + residual": lambda l, li, st: gemv(l.mlp.down_proj.weight, None, ptr(d.mid), x, ptr(scratch), D, I, st),
     }
     res = {}
     total = 0.0
-    if os.environ.get("DEC_SKIP_AO") == "1":
-        classes.pop("attention + o_proj, one launch")
     for name, fn in classes.items():
         g = graph_of(fn)
         t = timeit(g.replay) / len(m.model.layers)

@@ -4,6 +4,7 @@
 // forbid overlaps the real kernel has; the stamped build also waits for its stores before the last stamp). Build + run on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/probes/gemm_stamps.hip -o /tmp/gemm_stamps && /tmp/gemm_stamps
 #define MERV_GEMM_STAMPS 1
+#include "gemm_probe_hooks.h"
 #include "../../merv_amd/csrc/gemm.hip"
 #include "../../merv_amd/csrc/prof.cpp"
 
