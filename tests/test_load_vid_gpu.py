@@ -185,3 +185,120 @@ def test_eval_mcq_script_shape(tmp_path, dev, monkeypatch):
     expect = np.linspace(0, min(n_frames - 1, 595), max(num_frames), dtype=int).tolist()
     assert seen["kw"]["end_frame"] == 595 and seen["kw"]["num_frames"] == max(num_frames)
     assert seen["ids"] == expect == [0, 198, 396, 595]
+
+
+def test_eval_openended_script_shape(tmp_path, dev, monkeypatch):
+    """The loop of the reference's scripts/eval_openended.py:56-219, in its order, through the `merv` alias: questions / answers json,
+    `get_chunk`, `load_vid(run, hf_token=...)` + `.to(device, bf16)`, the resume file, then per question a fresh
+    `vidlm.llm_backbone.prompt_builder_fn(model_family="merv")` turn (with the "\\n<video>" suffix of the `_token` datasets),
+    `glob` for the video file by name, `vidlm.generate(video_name, prompt_text, do_sample=, temperature=, max_new_tokens=, min_length=,
+    num_frames=)` inside `try / except Exception: continue`, one jsonl line per answered question merged with its answer record, and
+    the final rename to `_done.jsonl`. One of the three videos is unreadable: the loop must print, skip it and go on (:189-192), and
+    the model must still answer the next question. The time-window form of the same call (`clip_start_sec` / `clip_end_sec`, as
+    eval_mcq.py passes them from question["time"]) is checked on a pre-decoded clip against datasets.py:131-136."""
+    import glob
+    import math
+    import os
+    import numpy as np
+    from PIL import Image
+    from merv.models.load_vid import load_vid
+    import merv_amd.video_io as vio
+
+    class Tok:
+        def __call__(self, text):
+            self.last_text = text
+            return [1] + [3 + (ord(c) % 200) for c in text][:24]
+
+        def decode(self, ids):
+            return " ".join(str(i) for i in ids)
+
+    # ---- eval_data/<benchmark>/{test_q,test_a}.json + videos/, as the script reads them (:62-77)
+    benchmark, eval_dataset = "MSVDsmall", "MSVDsmall_token"
+    data = tmp_path / "eval_data" / benchmark
+    (data / "videos").mkdir(parents=True)
+    questions = [{"question_id": f"q{i}", "video_name": f"vid{i}", "question": q} for i, q in
+                 enumerate(["what is the man doing?", "who is running?", "what color is the car?"])]
+    answers = [{"question_id": f"q{i}", "answer": a, "answer_type": 0} for i, a in enumerate(["cooking", "a dog", "red"])]
+    (data / "test_q.json").write_text(json.dumps(questions))
+    (data / "test_a.json").write_text(json.dumps(answers))
+    for i in (0, 2):
+        frames = [Image.fromarray(np.full((48, 64, 3), 20 * k + 5 * i, dtype=np.uint8)) for k in range(9)]
+        frames[0].save(data / "videos" / f"vid{i}.gif", save_all=True, append_images=frames[1:], duration=40, loop=0)
+    (data / "videos" / "vid1.gif").write_bytes(b"this is not a gif")  # the unreadable video
+
+    def split_list(lst, n):  # eval_openended.py:22-25
+        chunk_size = math.ceil(len(lst) / n)
+        return [lst[i:i + chunk_size] for i in range(0, len(lst), chunk_size)]
+
+    num_chunks, chunk_idx = 1, 0
+    qs = json.load(open(data / "test_q.json"))
+    all_questions_id = set(item["question_id"] for item in qs)
+    qs = split_list(qs, num_chunks)[chunk_idx]
+    answers_dict = {item["question_id"]: item for item in json.load(open(data / "test_a.json"))}
+
+    run, *_ = _write_run(tmp_path, dev)
+    tok = Tok()
+    vidlm, model_cfg = load_vid(str(run), hf_token="unused", get_model_cfg=True, llm_config=TINY_LLM, tokenizer=tok, device=dev)
+    vidlm.to(dev, dtype=torch.bfloat16)
+    num_frames = model_cfg["num_frames"] if isinstance(model_cfg, dict) else model_cfg.num_frames
+
+    result_dir = tmp_path / "eval_result" / "run"
+    os.makedirs(result_dir, exist_ok=True)
+    pred = result_dir / f"{eval_dataset}_pred_{num_chunks}_{chunk_idx}.jsonl"
+    done_lines, failed = [], []
+    with open(pred, "w") as f:
+        for line in done_lines:
+            f.write(line)
+        for i, question in enumerate(qs):
+            prompt_builder = vidlm.llm_backbone.prompt_builder_fn(model_family="merv")
+            message = question["question"] + ("\n<video>" if "_token" in eval_dataset else "")
+            prompt_builder.add_turn(role="human", message=message)
+            prompt_text = prompt_builder.get_prompt()
+            video_name = glob.glob(f"{data}/videos/{question['video_name']}.*")[0]
+            try:
+                generated_text = vidlm.generate(video_name, prompt_text, do_sample=False, temperature=1.0, max_new_tokens=6, min_length=1,
+                                                num_frames=num_frames)
+                question["pred"] = generated_text
+                question["message"] = message
+                question = {**question, **answers_dict[question["question_id"]]}
+                f.write(json.dumps(question) + "\n")
+            except Exception as e:  # if video loading has an issue (:189-192)
+                print(e)
+                failed.append(video_name)
+                continue
+    os.rename(pred, result_dir / f"{eval_dataset}_pred_{num_chunks}_{chunk_idx}_done.jsonl")
+    lines = [json.loads(l) for l in open(result_dir / f"{eval_dataset}_pred_{num_chunks}_{chunk_idx}_done.jsonl")]
+    assert [l["question_id"] for l in lines] == ["q0", "q2"] and len(failed) == 1 and failed[0].endswith("vid1.gif")
+    assert all(isinstance(l["pred"], str) and 1 <= len(l["pred"].split()) <= 6 for l in lines)
+    assert lines[0]["answer"] == "cooking" and lines[1]["answer"] == "red" and lines[1]["message"].endswith("\n<video>")
+    assert tok.last_text == f"In: {questions[2]['question']}\n<video>\nOut:"
+    assert all_questions_id - set(l["question_id"] for l in lines) == {"q1"}  # not merged: one question is still open (:211-218)
+    # the same question asked again gives the same greedy answer (the failed call in between left the decoder usable)
+    again = vidlm.generate(str(data / "videos" / "vid0.gif"), f"In: {questions[0]['question']}\n<video>\nOut:", do_sample=False, temperature=1.0,
+                           max_new_tokens=6, min_length=1, num_frames=num_frames)
+    assert again == lines[0]["pred"]
+
+    # ---- the time-window form: clip_start_sec / clip_end_sec in seconds select frames [start * fps, end * fps] (datasets.py:131-141)
+    n_frames, fps = 600, 25.0
+    idx = torch.arange(n_frames)
+    clip = torch.zeros(n_frames, 24, 32, 3, dtype=torch.uint8)
+    clip[..., 0] = (idx % 251)[:, None, None].to(torch.uint8)
+    clip[..., 2] = (idx // 251)[:, None, None].to(torch.uint8)
+    seen = {}
+    orig = vio.load_video
+
+    def spy(video, **kw):
+        out = orig(video, **kw)
+        seen["kw"] = kw
+        seen["ids"] = (out[:, 0, 0, 0].long() + 251 * out[:, 2, 0, 0].long()).tolist()
+        return out
+
+    monkeypatch.setattr(vio, "load_video", spy)
+    question = {"time": [4.0, 12.5]}
+    text = vidlm.generate((clip, fps), "In: what happens?\nOut:", do_sample=False, temperature=1.0, max_new_tokens=3, min_length=1,
+                          num_frames=num_frames, clip_start_sec=question["time"][0], clip_end_sec=question["time"][1])
+    assert isinstance(text, str)
+    # datasets.py:131-136: np.linspace(clip_start_sec * avg_fps, min(N - 1, clip_end_sec * avg_fps - 1), num_frames, dtype=int)
+    expect = np.linspace(4.0 * fps, min(n_frames - 1, 12.5 * fps - 1), max(num_frames), dtype=int).tolist()
+    assert seen["kw"]["clip_start_sec"] == 4.0 and seen["kw"]["clip_end_sec"] == 12.5
+    assert seen["ids"] == expect, (seen["ids"], expect)

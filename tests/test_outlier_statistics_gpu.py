@@ -1,0 +1,36 @@
+"""GPU: parity under the activation statistics of TRAINED towers (tools/parity_outliers.py has the method): outlier
+channels 100-1000 x the bulk's spread with small LayerNorm gains on them, token-local massive values, row means several times the
+bulk's spread, injected into the seeded towers at full depth. The folded-LayerNorm HIP path (the default), the separate-LayerNorm
+HIP path and the reference's own stack as PyTorch-ROCm bf16 ops, all against the fp32 CPU oracle on the same weights and pixels."""
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
+
+# bf16 bound under these statistics, bulk channels: the reference stack itself sits at ~ 1-2e-2 at depth 23 on Gaussian streams (DESIGN.md
+# section 3); measured values for the injected ones are in profiles/r05_parity_outliers.json
+BOUND_BULK = 2e-2
+
+
+@pytest.mark.parametrize("name", ["languagebind", "dinov2"])
+def test_full_depth_parity_with_outlier_channels_and_row_offsets(dev, name):
+    import parity_outliers as P
+    res = P.run(dev, encoders=(name,), scenarios=("both",), batch=16)[name]["both"]
+    print(name, res)
+    st = res["oracle_stream"]
+    assert st["outlier_channel_max_abs_over_bulk_spread"] >= 500 and st["always_on_channel_median_abs_over_bulk_spread"] >= 100
+    assert st["row_mean_over_bulk_spread"] >= 3.0  # the injected statistics are what the test says they are
+    assert res["depth"] == 23
+    fold, sep, ref = res["hip_ln_folded_vs_oracle"], res["hip_ln_separate_vs_oracle"], res["torch_rocm_bf16_vs_oracle"]
+    # a video gives the same bits alone and as the last of a 16-video batch (whose rows the remainder launches compute)
+    assert res["hip_batch_last_video_bit_equal_to_video_alone"] == {"hip_ln_folded": True, "hip_ln_separate": True}
+    for key in ("rel_l2", "rel_l2_bulk"):
+        assert fold[key] <= max(1.10 * ref[key], ref[key] + 5e-4), (key, fold, ref)  # not above the reference stack's own error
+        assert sep[key] <= max(1.10 * ref[key], ref[key] + 5e-4), (key, sep, ref)
+    assert fold["rel_l2_bulk"] <= BOUND_BULK and fold["min_cos_bulk"] >= 0.999, fold
