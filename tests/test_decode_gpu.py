@@ -522,7 +522,7 @@ def test_one_decoder_alternating_greedy_and_sampled_generations(dev):
     greedy = lambda: llm.generate_from_embeds(emb, max_new_tokens=19)
     ref = {}
     for name, fn in (("greedy", greedy), ("sample", sample), ("penal", penal)):  # each on a fresh decoder
-        llm._decoders.clear()
+        getattr(llm, "_decoders", {}).clear()
         ref[name] = fn()
     for order in (("greedy", "sample", "greedy", "penal", "greedy", "sample"), ("sample", "greedy", "penal", "greedy")):
         llm._decoders.clear()
