@@ -269,24 +269,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         };
         static_assert(NW == 4 && RES_KROWS == 264 && RES_VROWS == 272, "piece schedule below is written for these sizes");
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        // Pieces 0 .. 31 (rows 0 .. 255 < L: no clamp) take the scalar-base form of the instruction (round 5): the piece's first row is
-        // a wave-uniform pointer in SGPRs (scalar adds), the lane's part -- its row inside the piece and its swizzled chunk -- a 32-bit
-        // offset computed ONCE: a wave's K pieces 8 tq + wv and 8 tq + 4 + wv all have the parity of wv, so kswz(row) = (4 (pc & 1) +
-        // (rr >> 1)) & 7 is the same for all of them, and V's swizzle only depends on rr. The per-piece 64-bit address arithmetic per
-        // lane (~12 VALU instructions per piece, ahead of the loads it delays) is gone.
-        const unsigned off_k = (unsigned)(rr * ld + ((pcnk ^ ((4 * (wv & 1) + (rr >> 1)) & 7)) * 8)) * 2u;
-        const unsigned off_v = (unsigned)(rr * ld + ((pcnk ^ (((rr >> 1) & 1) << 2)) * 8)) * 2u;
-        auto glds16s = [&](const bf16_t* sbase, unsigned voff, unsigned lds_dst) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-        };
-        auto dma_k_fast = [&](int pc) { glds16s(kbase + (size_t)pc * 8 * ld, off_k, lds0 + pc * 1024); };            // pc < 32, pc & 1 == wv & 1
-        auto dma_v_fast = [&](int pc) { glds16s(vbase + (size_t)pc * 8 * ld, off_v, lds0 + K_BYTES + pc * 1024); };  // pc < 32
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq) {  // key tiles 0, 1: pieces 8 tq .. 8 tq + 7, two K and two V pieces per wave
-            dma_k_fast(8 * tq + wv); dma_k_fast(8 * tq + 4 + wv);
-            dma_v_fast(8 * tq + wv); dma_v_fast(8 * tq + 4 + wv);
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
         }
         // the BUILTIN form of the wait: hipcc's waitcnt pass sees it and retires the Q fragment loads in its own bookkeeping; after
         // an asm wait it would still count them and stall their first uses on the second-phase DMAs it cannot see
@@ -294,8 +280,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         __syncthreads();
 #pragma unroll
         for (int tq = 2; tq < 4; ++tq) {
-            dma_k_fast(8 * tq + wv); dma_k_fast(8 * tq + 4 + wv);
-            dma_v_fast(8 * tq + wv); dma_v_fast(8 * tq + 4 + wv);
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
         }
         if (wv == 0) dma_k(32);          // K rows 256 .. 263
         if (wv < 2) dma_v(32 + wv);      // V rows 256 .. 271
@@ -322,25 +308,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         for (int s = 0; s < 4; ++s) qx[s] = scale_q(qxraw[s]);
     }
     const float psum_limit = fast_exp2(p.rescale_thr);  // a lane's 32 exponentials may sum to this before its reference moves
-    // The reference -m enters the score chain as ONE MORE K-STEP (round 5) instead of 32 accumulator moves per tile: the k slots
-    // 8 h + j of that step hold {1, 1, 0, ..} on the key side and {hi, lo, 0, ..} on the query side in the h = 0 half-wave (zeros in the
-    // other), with hi + lo = -m as two bf16 terms, so the step adds exactly -m_eff = hi + lo to every score of the query. The kernel is
-    // VALU-issue-bound at head dim 64 (26 cycles of VALU against 16 of MFMA per score and lane, EXPERIMENTS.md section 2) and the matrix pipe
-    // is a quarter busy: one MFMA per 32-key block replaces 16 v_mov. m only has to be a consistent reference, so the running
-    // maximum is kept AS the two-term value (quantize_ref): the seed, the exact tile's own exponentials, the rescale factors and the
-    // extra rows' merge all use the same number.
-    const bf16x8 ones_k = __builtin_bit_cast(bf16x8, u32x4{h == 0 ? 0x3f803f80u : 0u, 0u, 0u, 0u});
-    auto quantize_ref = [&](float m, bf16x8& frag) -> float {  // m finite; returns m_eff, frag <- its B-operand fragment
-        const float nm = -m;
-        const uint32_t hi = f2bf(nm);
-        const float hif = __uint_as_float(hi << 16);
-        const uint32_t lo = f2bf(nm - hif);
-        frag = __builtin_bit_cast(bf16x8, u32x4{h == 0 ? (hi | (lo << 16)) : 0u, 0u, 0u, 0u});
-        return -(hif + __uint_as_float(lo << 16));
-    };
-    bf16x8 mneg[QPW];
-#pragma unroll
-    for (int qi = 0; qi < QPW; ++qi) mneg[qi] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
     // One key tile. TAILK (compile time): 0 = decide at run time whether the tile is the ragged last one; 1 = a full tile;
     // 2 = the resident kernel's last tile (sequences of 257 .. 264 tokens: 1 .. 8 keys, see tile_softmax).
     auto tile_body = [&](const int t, auto tailk_tag) {
@@ -370,19 +337,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         //      tiles the score registers would not fit and each tile is multiplied right before its softmax ----
         constexpr bool S_FIRST = QPW <= 2;
         f32x16 sacc[S_FIRST ? QPW : 1][2];
-        // seeded: the chain starts with the -m step (above) and ends on s' - m; otherwise on the raw s'
-        auto scores = [&](const bf16x8(&qfr)[4], f32x16(&sa)[2], const bool seeded, const bf16x8& mfrag) {
+        // seed: this lane's (= this query's) value for all 32 of its score registers: 0, or -m so that the chain ends on s' - m
+        auto scores = [&](const bf16x8(&qfr)[4], f32x16(&sa)[2], const float seed) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 if (kb == 1 && !both_halves) continue;
                 const int key = kb * 32 + r;
                 const char* krow = k_t + key * KROW;
                 const int sw = kswz(key);
-                f32x16 c0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) c0[i] = 0.f;
-                if (seeded) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_k, mfrag, c0, 0, 0, 0);
-                sa[kb] = c0;
+                for (int i = 0; i < 16; ++i) sa[kb][i] = seed;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = *(const bf16x8*)(krow + (((2 * s + h) ^ sw) * 16));
@@ -409,7 +373,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     }
             }
         };
-        auto tile_softmax = [&](auto ne_tag, f32x16(&sa)[2], float m_old, float& m_new, bf16x8& m_frag) -> float {
+        auto tile_softmax = [&](auto ne_tag, f32x16(&sa)[2], float m_old, float& m_new) -> float {
             constexpr int NE = decltype(ne_tag)::value;
             constexpr int NKB = NE == 16 ? 2 : 1;
             float mx = -INFINITY;
@@ -421,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 for (int i = 0; i < NE; ++i) mx = fmaxf(mx, sa[kb][i]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            m_new = quantize_ref(fmaxf(mx, m_old), m_frag);  // (an unchanged m_old comes back as itself: it is a two-term value already)
+            m_new = fmaxf(mx, m_old);
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -468,25 +432,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         // the first tile has no reference yet (m = -inf): seed 0 and the exact form
         if constexpr (S_FIRST) {
 #pragma unroll
-            for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi], t != 0, mneg[qi]);
+            for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi], t == 0 ? 0.f : -m_run[qi]);
         }
         using NE_t = std::integral_constant<int, TAILK == 2 ? 4 : 16>;
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
             if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
-            if constexpr (!S_FIRST) scores(qf[qi], sa, t != 0, mneg[qi]);
+            if constexpr (!S_FIRST) scores(qf[qi], sa, t == 0 ? 0.f : -m_run[qi]);
             // ---- online softmax (this lane: one query, 32 of the tile's 64 keys) ----
             float psum = 0.f;
             bool exact = t == 0;
             if (!exact) {
                 psum = tile_exp(NE_t{}, sa);
                 exact = !__all(psum <= psum_limit);  // (a NaN or an infinite sum fails the comparison too)
-                if (exact) scores(qf[qi], sa, false, mneg[qi]);  // rare: this tile again from its raw scores
+                if (exact) scores(qf[qi], sa, 0.f);  // rare: this tile again from its raw scores
             }
             if (exact) {
                 float m_new;
-                psum = tile_softmax(NE_t{}, sa, m_run[qi], m_new, mneg[qi]);
+                psum = tile_softmax(NE_t{}, sa, m_run[qi], m_new);
                 if (t > 0 && !__all(m_new == m_run[qi])) {  // the running max moved for some query of this wave: rescale
                     const float alpha = fast_exp2(m_run[qi] - m_new);
                     l_run[qi] *= alpha;
@@ -517,10 +481,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         if constexpr (XQ) {
             if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
                 f32x16 sx[2];
-                bf16x8 unused_frag;
-                scores(qx, sx, false, ones_k);
-                float mx;  // the tile's own reference (finite: key kv0 of every tile is a real key); partials are merged after the loop
-                const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sx, -INFINITY, mx, unused_frag);
+                scores(qx, sx, 0.f);
+                float mx;  // the tile's own maximum (finite: key kv0 of every tile is a real key); partials are merged after the loop
+                const float psum = tile_softmax(std::integral_constant<int, TAILK == 2 ? 4 : 16>{}, sx, -INFINITY, mx);
                 f32x16 ox[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { ox[0][i] = 0.f; ox[1][i] = 0.f; }

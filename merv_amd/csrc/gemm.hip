@@ -38,8 +38,9 @@
 #define MERV_PROBE_A_ROW(r, p) (r)               // A row a DMA piece reads
 #define MERV_PROBE_W_ROW(r, p) (r)               // W row a DMA piece reads
 #define MERV_PROBE_STORE_COND(p) true            // ANDed into the store predicate
+#define MERV_PROBE_STORE16(v, ptr) __builtin_nontemporal_store(v, ptr)  // the epilogue's 16-byte output stores (streaming: no L2 allocation)
 #define MERV_PROBE_SKIP_W_DMA(t) false           // eight-phase kernel: drop the W pieces of K-tile t
-#define MERV_PROBE_NO_EPILOGUE 0                 // eight-phase kernel: prologue + K-loop only
+#define MERV_PROBE_NO_EPILOGUE 0                 // prologue + K-loop only
 #define MERV_PROBE_DRAIN_STORES() do { } while (0)  // stamped builds wait for their stores before the last stamp
 #define MERV_PROBE_REST_MODE 0                   // launch_gemm: 0 remaining rows launched, 1 not computed, 2 an empty launch instead
 #define MERV_PROBE_REST_LAUNCH(s, e) (e)
@@ -340,7 +341,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             } else if (valid[it] && MERV_PROBE_STORE_COND(p)) {
                 // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
                 // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
-                __builtin_nontemporal_store(t, (u32x4*)(p.C + (size_t)c_off[it]));
+                MERV_PROBE_STORE16(t, (u32x4*)(p.C + (size_t)c_off[it]));
             }
         }
         if (p.stats_out) {
@@ -505,8 +506,8 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                 }
             } else if (valid[j] && MERV_PROBE_STORE_COND(p)) {
                 // streaming stores (no L2 allocation: see gemm_epilogue)
-                __builtin_nontemporal_store(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
-                __builtin_nontemporal_store(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
+                MERV_PROBE_STORE16(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
+                MERV_PROBE_STORE16(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
             }
         }
         if (p.stats_out) {  // one store of 16 MI consecutive float2 per part (layout [N / 64][M][2])
@@ -713,7 +714,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
         mma_half(haf, hwf, 0, 0, 0, std::false_type{});
     }
 
-    if constexpr (DIRECT) {
+    if constexpr (MERV_PROBE_NO_EPILOGUE) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (DIRECT) {
         static_assert(WTN == 64, "the direct epilogue pairs the four 16-column fragments of a 64-column wave tile");
         gemm_epilogue_direct<WTM, REMAP, ACT, EPI>(p, acc, lane, m0, n0, wr, wc);
     } else {

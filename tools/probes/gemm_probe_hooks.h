@@ -8,6 +8,7 @@
 //   MERV_ABL_WRAPROWS       every output / residual row wraps into the first 4096 rows (8 MB at N = 1024: stays in the L2s)
 //   MERV_ABL_WRAPOPS        operand rows wrap into g_probe_wrap_a / g_probe_wrap_w BYTES of A / W (runtime, 0 = off): the L2-resident
 //                           operand footprint of the energy-bound probe (same MFMAs, same LDS traffic, fabric operand traffic -> ~0)
+//   MERV_ABL_PLAINSTORE     L2-allocating output stores instead of the streaming (nontemporal) ones
 //   MERV_ABL_NOSTORE        the whole epilogue, but nothing is stored (the condition is a runtime value: nothing is dead code)
 //   MERV_ABL_HALFDMA        W pieces after K-tile 0 are never loaded (is the K-loop load-path-bound?)
 //   MERV_ABL_NOEPI          prologue + K-loop + block turnover only
@@ -69,6 +70,12 @@ __device__ int g_probe_wrap_a = 0, g_probe_wrap_w = 0;  // bytes of A / W the op
 #define MERV_PROBE_STORE_COND(p) ((p).group_m == 12345)
 #else
 #define MERV_PROBE_STORE_COND(p) true
+#endif
+
+#ifdef MERV_ABL_PLAINSTORE  // L2-allocating output stores instead of streaming ones
+#define MERV_PROBE_STORE16(v, ptr) (*(ptr) = (v))
+#else
+#define MERV_PROBE_STORE16(v, ptr) __builtin_nontemporal_store(v, ptr)
 #endif
 
 #ifdef MERV_ABL_HALFDMA
