@@ -499,7 +499,7 @@ extern "C" int merv_projector_forward(const void* tokens, int32_t batch, int32_t
                                       void* pooled_ws, void* out, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(tokens && proj_w && pooled_ws && out, "merv_projector_forward: null argument");
-    MERV_CHECK(batch > 0 && T > 0 && S > 0 && out_size > 0 && S >= out_size, "merv_projector_forward: bad geometry");
+    MERV_CHECK(batch > 0 && T > 0 && S > 0 && out_size > 0, "merv_projector_forward: bad geometry");  // S < out_size: AdaptiveAvgPool replicates (window rule unchanged)
     MERV_CHECK(C % 64 == 0 && llm_dim % 128 == 0, "merv_projector_forward: C % 64 and llm_dim % 128 required");
     hipStream_t s = (hipStream_t)stream_;
     PoolArgs pa{(const bf16_t*)tokens, (bf16_t*)pooled_ws, batch, T, S, out_size, C};

@@ -40,15 +40,22 @@ class MERVVisual(nn.Module):
                  visual_feature_length: int = 1024, concurrent_streams: bool = True) -> None:
         super().__init__()
         self.video_backbones = list(video_backbones)  # frozen, not registered as sub-modules (merv.py:315-381)
-        # The visual path drives the encoders' featurizers directly (patch tokens, projector geometry spec.t_out x spec.s_out);
-        # a backbone id whose forward() selects something else (class token, averages, class-token-first, pooled SigLIP) would
-        # silently be fused as plain patches. Those ids are served by VideoBackbone.forward() alone; MERV refuses them.
+        # The visual path drives the patch-token featurizers directly; a backbone id whose forward() selects something else
+        # (class token, per-frame average, pooled head: materialize.py:31-73) goes through its own forward() and the projector
+        # grid the reference derives from it (merv.py:576-585: [B, temporal_resolution, spatial_resolution, C], then
+        # nn_utils.py:320-330 with H = int(sqrt(spatial_resolution))). Selections the reference's own reshape / rearrange rejects
+        # (a class token in front of the patches: F * 256 + 1 tokens; 257 tokens per frame: not H x W) are rejected here as well.
+        self._selectors = []
         for vb in self.video_backbones:
-            if not getattr(vb, "selects_spec_patches", True):
-                raise NotImplementedError(
-                    f"MERV on the HIP path fuses patch-token backbones only; `{vb.identifier}` selects other tokens "
-                    f"(num_patches={vb.num_patches}). Use its forward() directly, or a patch-token id "
-                    "(languagebind-video-noclass, dinov2-video-all-tokens, vivit-google-b-all-no-cls-16frames, siglip-vit-b16-224px-all-no-cls).")
+            if getattr(vb, "selects_spec_patches", True):
+                self._selectors.append(None)
+                continue
+            S, T = vb.spatial_resolution, vb.temporal_resolution
+            side = int(S ** 0.5)
+            if side * side != S:
+                raise ValueError(f"`{vb.identifier}`: {S} tokens per frame do not form an H x W grid -- the reference's "
+                                 "AveragePooling3DProjector fails on it too (einops 'B F (H W) C', nn_utils.py:322-326)")
+            self._selectors.append((vb.forward, T, side))
         self.feature_fusion_type = feature_fusion
         torch.manual_seed(self.video_backbones[0].embed_dim)  # merv.py:87: projector-init consistency
         self.arch_specifier = arch_specifier
@@ -121,7 +128,7 @@ class MERVVisual(nn.Module):
             else:
                 self._path = MervVisualPath([vb.spec for vb in self.video_backbones], None, proj_w, self.feature_fusion, dev,
                                             out_size=self.projectors[0].output_size, concurrent_streams=self.concurrent,
-                                            encoders=[vb.featurizer for vb in self.video_backbones])
+                                            encoders=[vb.featurizer for vb in self.video_backbones], selectors=self._selectors)
             self._path_versions = ver
         return self._path
 

@@ -50,10 +50,15 @@ class MervVisualPath:
     def __init__(self, specs: Sequence[EncoderSpec], enc_weights: Optional[Sequence[Dict]],
                  proj_weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
                  fusion: Optional[CrossAttentionAdapterLearnableQuery], device, out_size: int = 8,
-                 concurrent_streams: bool = True, encoders: Optional[Sequence[HipEncoder]] = None):
+                 concurrent_streams: bool = True, encoders: Optional[Sequence[HipEncoder]] = None,
+                 selectors: Optional[Sequence[Optional[Tuple]]] = None):
         """`encoders`: already-resident HipEncoder objects (then `enc_weights` is ignored), else one is built per
         (spec, weight dict). `fusion=None` is the single-encoder form (merv.py:607: no fusion module): forward returns
-        the lone projector's output and weights None."""
+        the lone projector's output and weights None.
+        `selectors[i]` = (fn, T, side) for a backbone whose forward() is NOT the plain patch selection (registry ids with a class-token /
+        averaged / pooled selection, materialize.py:31-73): `fn(pixels) -> [B, T * side * side, C]` bf16 on the current stream replaces the
+        encoder's patch-token output and (T, side) the projector's grid (merv.py:576-585: reshape to [B, temporal_resolution,
+        spatial_resolution, C]; nn_utils.py:320-330 pools it to (T, 8, 8), replicating when side < 8). None: the spec's patches."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("MervVisualPath needs a ROCm device; merv_amd has no CPU path")
@@ -69,7 +74,8 @@ class MervVisualPath:
                 self.encoders = [HipEncoder(s, w, self.device) for s, w in zip(specs, enc_weights)]
             self.out_size = out_size
             self.set_parameters(proj_weights, fusion)
-        self.tokens_out = {s.t_out * out_size * out_size for s in specs}
+        self.selectors = list(selectors) if selectors is not None else [None] * len(self.specs)
+        self.tokens_out = {(s.t_out if sel is None else sel[1]) * out_size * out_size for s, sel in zip(specs, self.selectors)}
         if len(self.tokens_out) != 1:  # merv.py:175-193 consistency assert
             raise ValueError(f"Output token length is not consistent across projectors: {self.tokens_out}")
         self.T_vis = self.tokens_out.pop()
@@ -103,11 +109,16 @@ class MervVisualPath:
     def _enc_bufs(self, i: int, B: int, frames: Optional[int] = None) -> Dict[str, torch.Tensor]:
         s = self.specs[i]
         t_out = s.t_out if frames is None else frames // s.tubelet
+        s_out = s.s_out
+        if self.selectors[i] is not None:
+            if frames is not None:
+                raise ValueError(f"{s.name}: frame-range units need the plain patch selection")
+            t_out, s_out = self.selectors[i][1], self.selectors[i][2] ** 2
         key = (i, B, t_out)
         if key not in self._bufs:
             o = self.out_size
             self._bufs[key] = {
-                "tokens": torch.empty(B, t_out * s.s_out, s.dim, dtype=torch.bfloat16, device=self.device),
+                "tokens": torch.empty(B, t_out * s_out, s.dim, dtype=torch.bfloat16, device=self.device),
                 "pooled": torch.empty(B * t_out * o * o, s.dim, dtype=torch.bfloat16, device=self.device),
                 "proj": torch.empty(B, t_out * o * o, self.llm_dim, dtype=torch.bfloat16, device=self.device),
             }
@@ -133,11 +144,19 @@ class MervVisualPath:
             if stream is None:
                 stream = torch.cuda.current_stream(self.device)
             bufs = self._enc_bufs(i, B, frames)
-            tok = self.encoders[i].forward(pixels, out=bufs["tokens"], stream=stream, frames=frames)
+            t_out, side = (s.t_out if frames is None else frames // s.tubelet), s.hp
+            if self.selectors[i] is None:
+                tok = self.encoders[i].forward(pixels, out=bufs["tokens"], stream=stream, frames=frames)
+            else:  # the backbone's own forward() (encoder + token selection) on this branch's stream, into the persistent buffer
+                fn, t_out, side = self.selectors[i]
+                with torch.cuda.stream(stream):
+                    sel = fn(pixels)
+                    if sel.numel() != bufs["tokens"].numel():  # the reference's reshape(-1, T, S, C) (merv.py:576-585) would fail too
+                        raise RuntimeError(f"{s.name}: forward() returned {tuple(sel.shape)}, which is not [B, {t_out} * {side * side}, {s.dim}]")
+                    tok = bufs["tokens"].copy_(sel.reshape(bufs["tokens"].shape))
             dst = out if out is not None else bufs["proj"]
             w, b = self.proj[i]
-            t_out = s.t_out if frames is None else frames // s.tubelet
-            rc = self.lib.merv_projector_forward(ptr(tok), B, t_out, s.hp, s.dim, self.out_size, ptr(w), ptr(b),
+            rc = self.lib.merv_projector_forward(ptr(tok), B, t_out, side, s.dim, self.out_size, ptr(w), ptr(b),
                                                  self.llm_dim, ptr(bufs["pooled"]), ptr(dst), stream.cuda_stream)
             check(rc, "merv_projector_forward")
         return dst
@@ -168,6 +187,8 @@ class MervVisualPath:
         def branch(i, pix, st):
             if project:
                 return self.encode_project(i, pix, st)
+            if self.selectors[i] is not None:
+                raise NotImplementedError(f"{self.specs[i].name}: encode_tokens() (the training step) drives plain patch selections only")
             bufs = self._enc_bufs(i, pix.shape[0])
             return self.encoders[i].forward(pix, out=bufs["tokens"], stream=st)
 

@@ -469,9 +469,11 @@ def test_temporal_subsample_matches_the_reference_generate_body():
             assert temporal_subsample(c["frames_loaded"], max(c["num_frames"]), nf) == sel, c
 
 
-def test_merv_refuses_backbones_whose_forward_is_not_the_patch_selection():
+def test_merv_routes_backbones_whose_forward_is_not_the_patch_selection():
     """the visual path drives featurizers directly, so an id that selects class tokens / averages / a pooled head
-    must not be fused silently as plain patches (merv.py:563-585 calls vb.forward and reshapes by vb's own resolutions)."""
+    must not be fused silently as plain patches (merv.py:563-585 calls vb.forward and reshapes by vb's own resolutions). Since round 5
+    such an id goes through its own forward() and the grid the reference derives from it (tests/test_vidlm_gpu.py); what the
+    reference's own projector rejects (257 tokens per frame: not H x W) is rejected here too."""
     from merv_amd import backbones as BB
     from merv_amd.vidlm import MERVVisual
 
@@ -496,9 +498,12 @@ def test_merv_refuses_backbones_whose_forward_is_not_the_patch_selection():
     }
     assert [k for k, v in sel.items() if v] == ["languagebind-video-noclass", "dinov2-video-all-tokens",
                                                 "vivit-google-b-all-no-cls-16frames", "siglip-vit-b16-224px-all-no-cls"]
-    vb = bare(BB.LangBindVideoBackbone, token="classemb", identifier="languagebind-video-classemb", num_frames=16)
-    with pytest.raises(NotImplementedError, match="patch-token backbones only"):
+    vb = bare(BB.LangBindVideoBackbone, token=None, identifier="languagebind-video", num_frames=16)
+    assert (vb.num_patches, vb.spatial_resolution, vb.temporal_resolution) == (16 * 257, 257, 16)
+    with pytest.raises(ValueError, match="do not form an H x W grid"):
         MERVVisual([vb])
+    cls = bare(BB.LangBindVideoBackbone, token="classemb", identifier="languagebind-video-classemb", num_frames=16)
+    assert (cls.num_patches, cls.spatial_resolution, cls.temporal_resolution) == (16, 1, 16)  # one token per frame: a 1 x 1 grid, pooled up to 8 x 8
 
 
 def test_bos_token_length_is_decided_by_the_tokenizer_like_the_reference():
