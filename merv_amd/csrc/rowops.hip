@@ -580,7 +580,7 @@ hipError_t launch_mean_rows(const MeanRowsArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_pool(const PoolArgs& a, hipStream_t s) {
-    if (a.C % 8 != 0 || a.Ho <= 0 || a.S < a.Ho) return hipErrorInvalidValue;
+    if (a.C % 8 != 0 || a.Ho <= 0 || a.S <= 0) return hipErrorInvalidValue;  // S < Ho: windows [floor(i S / Ho), ceil((i + 1) S / Ho)) replicate
     const long long total = (long long)a.B * a.T * a.Ho * a.Ho * (a.C / 8);
     if (total <= 0) return hipSuccess;
     ProfScope pk(PROF_K_POOLFUSE, s, 0.0, 2.0 * a.B * a.T * ((double)a.S * a.S + (double)a.Ho * a.Ho) * a.C);
