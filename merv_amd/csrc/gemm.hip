@@ -231,6 +231,24 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         }
     }
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
+    // MSPLIT >= 4 (A/B builds, -DMERV_GEMM_EPI_PARTS=4): residual rows are requested ONE PART AHEAD -- part p + 1's loads are issued
+    // before part p is staged and stored, into the other half of a two-part register buffer (the registers of one part of twice the rows)
+    constexpr bool PIPE = MSPLIT >= 4;
+    u32x4 res_ahead[PIPE ? 2 : 1][EP_IT];
+    auto res_rows = [&](int part, u32x4(&dst)[EP_IT]) {
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int m = m0 + wr * WTM_FULL + part * WTM + (elane >> 3) + 8 * it;
+            int rr = m < p.M ? m : p.M - 1;
+            if constexpr (REMAP) {
+                if (p.res_row_mod > 0) rr = rr % p.res_row_mod;
+            }
+            dst[it] = p.res ? *(const u32x4*)(p.res + (size_t)((uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + wn0 + ec * 8)) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    if constexpr (PIPE) {
+        if (p.res) res_rows(0, res_ahead[0]);
+    }
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
         if (part == 1) MERV_GSTAMP(8);  // part 0's stores are issued
@@ -254,7 +272,13 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         }
         // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
         // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
-        if (p.res) {
+        if constexpr (PIPE) {
+            if (p.res) {  // (uniform) this part's rows were requested a part ago; request the next part's
+                if (part + 1 < MSPLIT) res_rows(part + 1, res_ahead[(part + 1) & 1]);
+#pragma unroll
+                for (int it = 0; it < EP_IT; ++it) resv[it] = res_ahead[part & 1][it];
+            }
+        } else if (p.res) {
 #pragma unroll
             for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
         } else {
@@ -525,6 +549,11 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
 // launches (half-line streaming stores). A/B builds: -DMERV_GEMM_EPILOGUE=0 (always through LDS) / 1 (always direct).
 #ifndef MERV_GEMM_EPILOGUE
 #define MERV_GEMM_EPILOGUE 2
+#endif
+// Parts the eight-phase kernel's LDS epilogue finishes a wave's 128 rows in: 2 x 64 rows, each part requesting its own residual rows
+// (rounds 2-5); -DMERV_GEMM_EPI_PARTS=4: 4 x 32 rows with the residual rows requested one part ahead (round-5 A/B form, EXPERIMENTS.md section 1).
+#ifndef MERV_GEMM_EPI_PARTS
+#define MERV_GEMM_EPI_PARTS 2
 #endif
 template <int ACT>
 constexpr bool gemm_direct_epilogue = (MERV_GEMM_EPILOGUE == 1) || (MERV_GEMM_EPILOGUE == 2 && ACT != ACT_NONE);
@@ -1037,7 +1066,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     } else if constexpr (DIRECT) {
         gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
     } else {
-        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 2>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, MERV_GEMM_EPI_PARTS>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
     MERV_GSTAMP(10);  // part 1's stores are issued
     MERV_PROBE_DRAIN_STORES();
