@@ -106,7 +106,7 @@ def gemm_class_clocks():
         doc = json.loads(f.read_text())
         acc = {}
         for sh in doc["shapes"]:
-            prod = next(m for m in sh["modes"] if m["wrap_a_bytes"] == 0 and m["wrap_w_bytes"] == 0)
+            prod = next(m for m in sh["modes"] if m["wrap_a_bytes"] == 0 and m["wrap_w_bytes"] == 0 and not m.get("a_blocked"))
             w = float(sh["M"]) * sh["N"] * sh["K"]
             a = acc.setdefault(sh["class"], [0.0, 0.0])
             a[0] += w * prod["clock_ghz"]; a[1] += w

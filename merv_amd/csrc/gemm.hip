@@ -37,6 +37,8 @@
 #define MERV_PROBE_OUT_ROW(r) (r)                // output / residual row an epilogue access goes to
 #define MERV_PROBE_A_ROW(r, p) (r)               // A row a DMA piece reads
 #define MERV_PROBE_W_ROW(r, p) (r)               // W row a DMA piece reads
+#define MERV_PROBE_A_OFFSET(r, p, es) ((size_t)(r) * (p).lda * (es))  // byte offset of A row r at k = 0 (eight-phase kernel)
+#define MERV_PROBE_A_KSTEP ROW_BYTES             // bytes between consecutive K-tiles of an A row
 #define MERV_PROBE_STORE_COND(p) true            // ANDed into the store predicate
 #define MERV_PROBE_STORE16(v, ptr) __builtin_nontemporal_store(v, ptr)  // the epilogue's 16-byte output stores (streaming: no L2 allocation)
 #define MERV_PROBE_SKIP_W_DMA(t) false           // eight-phase kernel: drop the W pieces of K-tile t
@@ -822,7 +824,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
             int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
             grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
             grow = MERV_PROBE_A_ROW(grow, p);
-            a_src[sq][u] = (const char*)p.A + (size_t)grow * p.lda * ES + sw8;
+            a_src[sq][u] = (const char*)p.A + MERV_PROBE_A_OFFSET(grow, p, ES) + sw8;
             // LDS row slot ((wave >> 2) + 2 u) * 64 + sq * 32 + (wave & 3) * 8 + r8; DIRECT: it receives the permuted W row
             const int s32 = (wave & 3) * 8 + r8;
             const int nrow = MERV_PROBE_W_ROW(n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32), p);
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     };
     auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * MERV_PROBE_A_KSTEP, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
         if (MERV_PROBE_SKIP_W_DMA(t)) return;

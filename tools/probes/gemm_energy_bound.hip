@@ -13,6 +13,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Imerv_amd/csrc tools/probes/gemm_energy_bound.hip -o /tmp/geb && /tmp/geb > out.json
 #define MERV_GEMM_STAMPS_LIGHT 1
 #define MERV_ABL_WRAPOPS 1
+#define MERV_ABL_ABLOCKED 1
 #include "gemm_probe_hooks.h"
 #include "../../merv_amd/csrc/gemm.hip"
 #include "../../merv_amd/csrc/prof.cpp"
@@ -31,7 +32,7 @@ static uint16_t f2b(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(
 static double median(std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; }
 
 struct Shape { const char* name; const char* cls; int M, N, K, act; bool res, fold, stats; };
-struct Mode { const char* name; int wrap_a, wrap_w; };
+struct Mode { const char* name; int wrap_a, wrap_w, a_blocked; };
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 7;
@@ -47,8 +48,9 @@ int main(int argc, char** argv) {
         {"vivit fc1  N=3072 K=768 folded LayerNorm + tanh-GELU", "gemm eight-phase + activation epilogue", MVV, 3072, 768, merv::ACT_GELU_TANH, false, true, false},
         {"vivit fc2  N=768 K=3072 bias+residual+statistics", "gemm eight-phase, no activation", MVV, 768, 3072, merv::ACT_NONE, true, false, true},
     };
-    const Mode modes[] = {{"product mapping", 0, 0}, {"W rows wrapped into 1 MB", 0, 1 << 20}, {"A rows wrapped into 1.5 MB", 3 << 19, 0},
-                          {"A and W wrapped (1.5 + 1 MB per L2)", 3 << 19, 1 << 20}};
+    const Mode modes[] = {{"product mapping", 0, 0, 0}, {"W rows wrapped into 1 MB", 0, 1 << 20, 0}, {"A rows wrapped into 1.5 MB", 3 << 19, 0, 0},
+                          {"A and W wrapped (1.5 + 1 MB per L2)", 3 << 19, 1 << 20, 0},
+                          {"A read K-tile-blocked ([m-tile][K-tile][256 rows x 128 B]: 32 KB contiguous per piece set)", 0, 0, 1}};
     const int NM = sizeof(modes) / sizeof(modes[0]);
     const size_t MMAX = MLB;
     std::mt19937 rng(1);
@@ -82,6 +84,7 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         hipMemcpyToSymbol(HIP_SYMBOL(g_probe_wrap_a), &m.wrap_a, sizeof(int));
         hipMemcpyToSymbol(HIP_SYMBOL(g_probe_wrap_w), &m.wrap_w, sizeof(int));
+        hipMemcpyToSymbol(HIP_SYMBOL(g_probe_a_blocked), &m.a_blocked, sizeof(int));
         hipDeviceSynchronize();
     };
     printf("{\"what\": \"eight-phase GEMM, operand rows wrapped into an L2-resident footprint against the product mapping: wall time per launch and in-kernel clock\",\n");
@@ -146,7 +149,7 @@ int main(int argc, char** argv) {
             const double w = median(wall[m]);
             printf("    {\"mode\": \"%s\", \"wrap_a_bytes\": %d, \"wrap_w_bytes\": %d, \"us_per_launch_median\": %.2f, \"us_per_launch_min\": %.2f, \"tflops\": %.1f, "
                    "\"clock_ghz\": %.3f, \"block_life_us\": %.2f, \"speedup_vs_product\": %.4f}%s\n",
-                   modes[m].name, modes[m].wrap_a, modes[m].wrap_w, w, *std::min_element(wall[m].begin(), wall[m].end()), flop / w / 1e6, median(clk[m]),
+                   modes[m].name, modes[m].wrap_a, modes[m].wrap_w, modes[m].a_blocked, w, *std::min_element(wall[m].begin(), wall[m].end()), flop / w / 1e6, median(clk[m]),
                    median(life[m]), base / w, m + 1 < NM ? "," : "");
         }
         printf("  ]}");

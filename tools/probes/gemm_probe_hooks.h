@@ -9,6 +9,7 @@
 //   MERV_ABL_WRAPOPS        operand rows wrap into g_probe_wrap_a / g_probe_wrap_w BYTES of A / W (runtime, 0 = off): the L2-resident
 //                           operand footprint of the energy-bound probe (same MFMAs, same LDS traffic, fabric operand traffic -> ~0)
 //   MERV_ABL_PLAINSTORE     L2-allocating output stores instead of the streaming (nontemporal) ones
+//   MERV_ABL_ABLOCKED       the eight-phase kernel reads A in a K-tile-blocked layout (g_probe_a_blocked, runtime): contiguous 32 KB per (m-tile, K-tile)
 //   MERV_ABL_NOSTORE        the whole epilogue, but nothing is stored (the condition is a runtime value: nothing is dead code)
 //   MERV_ABL_HALFDMA        W pieces after K-tile 0 are never loaded (is the K-loop load-path-bound?)
 //   MERV_ABL_NOEPI          prologue + K-loop + block turnover only
@@ -64,6 +65,15 @@ __device__ int g_probe_wrap_a = 0, g_probe_wrap_w = 0;  // bytes of A / W the op
 #else
 #define MERV_PROBE_A_ROW(r, p) (r)
 #define MERV_PROBE_W_ROW(r, p) (r)
+#endif
+
+#ifdef MERV_ABL_ABLOCKED  // A read as if stored [m-tile of 256 rows][K-tile][256 rows x 128 B] when g_probe_a_blocked != 0 (timing only: random data)
+__device__ int g_probe_a_blocked = 0;
+#define MERV_PROBE_A_OFFSET(r, p, es) (g_probe_a_blocked ? ((size_t)((r) >> 8) * ((p).K / 64) * 32768 + (size_t)((r) & 255) * 128) : (size_t)(r) * (p).lda * (es))
+#define MERV_PROBE_A_KSTEP (g_probe_a_blocked ? 32768 : 128)
+#else
+#define MERV_PROBE_A_OFFSET(r, p, es) ((size_t)(r) * (p).lda * (es))
+#define MERV_PROBE_A_KSTEP 128
 #endif
 
 #ifdef MERV_ABL_NOSTORE
