@@ -834,9 +834,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
+    const int a_kstep = MERV_PROBE_A_KSTEP;  // (product: the constant ROW_BYTES)
     auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * MERV_PROBE_A_KSTEP, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * a_kstep, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
         if (MERV_PROBE_SKIP_W_DMA(t)) return;

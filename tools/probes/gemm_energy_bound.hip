@@ -147,7 +147,7 @@ int main(int argc, char** argv) {
         const double base = median(wall[0]);
         for (int m = 0; m < NM; ++m) {
             const double w = median(wall[m]);
-            printf("    {\"mode\": \"%s\", \"wrap_a_bytes\": %d, \"wrap_w_bytes\": %d, \"us_per_launch_median\": %.2f, \"us_per_launch_min\": %.2f, \"tflops\": %.1f, "
+            printf("    {\"mode\": \"%s\", \"wrap_a_bytes\": %d, \"wrap_w_bytes\": %d, \"a_blocked\": %d, \"us_per_launch_median\": %.2f, \"us_per_launch_min\": %.2f, \"tflops\": %.1f, "
                    "\"clock_ghz\": %.3f, \"block_life_us\": %.2f, \"speedup_vs_product\": %.4f}%s\n",
                    modes[m].name, modes[m].wrap_a, modes[m].wrap_w, modes[m].a_blocked, w, *std::min_element(wall[m].begin(), wall[m].end()), flop / w / 1e6, median(clk[m]),
                    median(life[m]), base / w, m + 1 < NM ? "," : "");

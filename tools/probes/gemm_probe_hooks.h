@@ -70,7 +70,7 @@ __device__ int g_probe_wrap_a = 0, g_probe_wrap_w = 0;  // bytes of A / W the op
 #ifdef MERV_ABL_ABLOCKED  // A read as if stored [m-tile of 256 rows][K-tile][256 rows x 128 B] when g_probe_a_blocked != 0 (timing only: random data)
 __device__ int g_probe_a_blocked = 0;
 #define MERV_PROBE_A_OFFSET(r, p, es) (g_probe_a_blocked ? ((size_t)((r) >> 8) * ((p).K / 64) * 32768 + (size_t)((r) & 255) * 128) : (size_t)(r) * (p).lda * (es))
-#define MERV_PROBE_A_KSTEP (g_probe_a_blocked ? 32768 : 128)
+#define MERV_PROBE_A_KSTEP __builtin_amdgcn_readfirstlane(g_probe_a_blocked ? 32768 : 128)  // read once, ahead of the K-loop
 #else
 #define MERV_PROBE_A_OFFSET(r, p, es) ((size_t)(r) * (p).lda * (es))
 #define MERV_PROBE_A_KSTEP 128
