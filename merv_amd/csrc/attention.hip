@@ -354,11 +354,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 }
             }
         };
-#ifdef MERV_ATTN_MFMA_PRIO  // A/B builds: the wave's MFMA groups at raised priority against its SIMD partner's VALU stream
-#define MERV_ATTN_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define MERV_ATTN_PRIO(x) do { } while (0)
-#endif
         // One lane's share of a score tile (scores s' in log2 units, seed 0) -> exponentials against the exact running maximum in
         // place, returns their sum; m_new = max(m_old, tile max).
         // NE = 16: elements of both 32-key halves (the second only when it holds real keys), masked on the tail tile.
@@ -436,10 +431,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         };
         // the first tile has no reference yet (m = -inf): seed 0 and the exact form
         if constexpr (S_FIRST) {
-            MERV_ATTN_PRIO(1);
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi], t == 0 ? 0.f : -m_run[qi]);
-            MERV_ATTN_PRIO(0);
         }
         using NE_t = std::integral_constant<int, TAILK == 2 ? 4 : 16>;
 #pragma unroll
@@ -469,7 +462,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
             l_run[qi] += psum;
 
             // ---- O^T += V^T P^T ----
-            MERV_ATTN_PRIO(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 if (kb == 1 && !both_halves) continue;
@@ -485,7 +477,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     }
                 }
             }
-            MERV_ATTN_PRIO(0);
         }
         if constexpr (XQ) {
             if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
