@@ -130,7 +130,7 @@ MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u3
 constexpr int XQ_ROWS = 8, XQ_SLOTS = 5;
 constexpr int RES_KROWS = 264, RES_VROWS = 272;  // K rows past 264 are read (and masked) from whatever follows; V rows must be finite
 template <bool VTR, int NW, int QPW, bool XQ = false, bool RES = false>
-__global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_kernel(AttnArgs p) {  // (second argument: waves per SIMD)
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     static_assert(!RES || (VTR && XQ && NW * QPW * 32 == 256), "resident form: 4 x 2 block with the extra-row split only");
     constexpr int NT = NW * 64;
     constexpr int V_BYTES = RES ? RES_VROWS * 128 : (VTR ? 64 * VROW_TR : 64 * VT_ROW);
@@ -172,16 +172,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
         for (int s = 0; s < 4; ++s) qraw[qi][s] = ld16(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
     }
     constexpr int XQ0 = NW * QPW * 32;  // first extra query row (XQ launches have one block per (sequence, head))
-    // XQ_LATE (one query tile per wave: the eight-wave resident form): the extra rows' pass runs AFTER the wave's own key-tile loop --
-    // wave t against key tile t -- so its score / output set re-uses the loop's registers instead of living beside them (the interleaved
-    // form needs both sets at once: 128 VGPRs + 220 B of scratch in round 3), and their Q rows are requested before the last key tile
-    constexpr bool XQ_LATE = XQ && QPW == 1;
-    auto load_qx = [&]() {
+    if constexpr (XQ) {
         const int q_ld = XQ0 + r < L ? XQ0 + r : L - 1;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qxraw[s] = ld16(base + (size_t)q_ld * ld + head * HD + 16 * s + 8 * h);
-    };
-    if constexpr (XQ && !XQ_LATE) load_qx();
+    }
 
     f32x16 oacc[QPW][2];
     float m_run[QPW], l_run[QPW];
@@ -272,14 +267,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
             const int grow = row < L ? row : L - 1;
             glds16(vbase + (size_t)grow * ld + ((pcnk ^ (((row >> 1) & 1) << 2)) * 8), lds0 + K_BYTES + pc * 1024);
         };
-        static_assert((NW == 4 || NW == 8) && RES_KROWS == 264 && RES_VROWS == 272, "piece schedule below is written for these sizes");
+        static_assert(NW == 4 && RES_KROWS == 264 && RES_VROWS == 272, "piece schedule below is written for these sizes");
         const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-        for (int tq = 0; tq < 2; ++tq) {  // key tiles 0, 1: pieces 8 tq .. 8 tq + 7, 8 / NW K and V pieces per wave
-#pragma unroll
-            for (int u = 0; u < 8 / NW; ++u) dma_k(8 * tq + NW * u + wv);
-#pragma unroll
-            for (int u = 0; u < 8 / NW; ++u) dma_v(8 * tq + NW * u + wv);
+        for (int tq = 0; tq < 2; ++tq) {  // key tiles 0, 1: pieces 8 tq .. 8 tq + 7, two K and two V pieces per wave
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
         }
         // the BUILTIN form of the wait: hipcc's waitcnt pass sees it and retires the Q fragment loads in its own bookkeeping; after
         // an asm wait it would still count them and stall their first uses on the second-phase DMAs it cannot see
@@ -287,10 +280,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
         __syncthreads();
 #pragma unroll
         for (int tq = 2; tq < 4; ++tq) {
-#pragma unroll
-            for (int u = 0; u < 8 / NW; ++u) dma_k(8 * tq + NW * u + wv);
-#pragma unroll
-            for (int u = 0; u < 8 / NW; ++u) dma_v(8 * tq + NW * u + wv);
+            dma_k(8 * tq + wv); dma_k(8 * tq + 4 + wv);
+            dma_v(8 * tq + wv); dma_v(8 * tq + 4 + wv);
         }
         if (wv == 0) dma_k(32);          // K rows 256 .. 263
         if (wv < 2) dma_v(32 + wv);      // V rows 256 .. 271
@@ -312,17 +303,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
     for (int qi = 0; qi < QPW; ++qi)
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[qi][s] = scale_q(qraw[qi][s]);
-    if constexpr (XQ && !XQ_LATE) {
+    if constexpr (XQ) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qx[s] = scale_q(qxraw[s]);
     }
     const float psum_limit = fast_exp2(p.rescale_thr);  // a lane's 32 exponentials may sum to this before its reference moves
     // One key tile. TAILK (compile time): 0 = decide at run time whether the tile is the ragged last one; 1 = a full tile;
     // 2 = the resident kernel's last tile (sequences of 257 .. 264 tokens: 1 .. 8 keys, see tile_softmax).
-    // xq_tag: 0 = the wave's own query tiles (and, interleaved form, the extra rows when t % NW == wave); 1 = the extra rows only (XQ_LATE)
-    auto tile_body = [&](const int t, auto tailk_tag, auto xq_tag) {
+    auto tile_body = [&](const int t, auto tailk_tag) {
         constexpr int TAILK = decltype(tailk_tag)::value;
-        constexpr bool XQ_ONLY = decltype(xq_tag)::value == 1;
         const int kv0 = t * 64;
         if constexpr (!RES) {
             __syncthreads();  // previous tile's LDS reads are done
@@ -333,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
             MERV_STAMP(4 + 4 * t);
             if (t + 1 < ntiles) load_tile(kv0 + 64);
         }
-        if constexpr (RES && !XQ_ONLY) {
+        if constexpr (RES) {
             if (t == 2) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // key tiles 2 .. 4 have landed (every wave's share)
         }
         const char* k_t = RES ? k_lds + kv0 * KROW : k_lds;  // this key tile's rows
@@ -441,13 +430,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
             return psum;
         };
         // the first tile has no reference yet (m = -inf): seed 0 and the exact form
-        if constexpr (S_FIRST && !XQ_ONLY) {
+        if constexpr (S_FIRST) {
 #pragma unroll
             for (int qi = 0; qi < QPW; ++qi) scores(qf[qi], sacc[qi], t == 0 ? 0.f : -m_run[qi]);
         }
         using NE_t = std::integral_constant<int, TAILK == 2 ? 4 : 16>;
 #pragma unroll
-        for (int qi = 0; qi < (XQ_ONLY ? 0 : QPW); ++qi) {
+        for (int qi = 0; qi < QPW; ++qi) {
             if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
             if constexpr (!S_FIRST) scores(qf[qi], sa, t == 0 ? 0.f : -m_run[qi]);
@@ -489,8 +478,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
                 }
             }
         }
-        if constexpr (XQ && (XQ_ONLY || !XQ_LATE)) {
-            if (XQ_ONLY || t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
+        if constexpr (XQ) {
+            if (t % NW == wave) {  // wave-uniform: this wave multiplies the extra rows against key tile t, once, start to finish
                 f32x16 sx[2];
                 scores(qx, sx, 0.f);
                 float mx;  // the tile's own maximum (finite: key kv0 of every tile is a real key); partials are merged after the loop
@@ -525,22 +514,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && QPW == 1) ? 4 : 2) void attn_k
         }
         MERV_STAMP(5 + 4 * t);
     };
-    using Main_t = std::integral_constant<int, 0>;
     if constexpr (RES) {  // L in (256, 264]: four full tiles, then the 1 .. 8 keys of the fifth
-        for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{}, Main_t{});
-        if constexpr (XQ_LATE) load_qx();  // lands under the tail tile
-        tile_body(ntiles - 1, std::integral_constant<int, 2>{}, Main_t{});
-        if constexpr (XQ_LATE) {
-            static_assert(NW >= 5, "one wave per key tile");
-            if (wave < ntiles) {  // wave-uniform: wave t multiplies the extra rows against key tile t
-#pragma unroll
-                for (int s = 0; s < 4; ++s) qx[s] = scale_q(qxraw[s]);
-                if (wave == ntiles - 1) tile_body(wave, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
-                else tile_body(wave, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-            }
-        }
+        for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{});
+        tile_body(ntiles - 1, std::integral_constant<int, 2>{});
     } else {
-        for (int t = 0; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{}, Main_t{});
+        for (int t = 0; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{});
     }
     MERV_STAMP(30);
 
@@ -1041,7 +1019,6 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     // 8 full tiles + 1..8 rows (257 / 261 tokens): 4 x 2 block, the extra rows split over the waves by key tile
     if (a.L > 256 && a.L <= 256 + XQ_ROWS && !a.mx_q) {
         if (force && force[0] == 'x') return launch_attn_cfg<4, 2, true>(a, s);  // streamed K / V tiles (A/B of the resident form)
-        if (force && force[0] == '8') return launch_attn_cfg<8, 1, true, true>(a, s);  // resident, eight waves x one tile, extra rows after the loop (A/B)
         if (use_vtr()) return launch_attn_cfg<4, 2, true, true>(a, s);           // all K / V rows resident in LDS
         return launch_attn_cfg<4, 2, true>(a, s);
     }
