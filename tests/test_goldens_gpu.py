@@ -58,6 +58,19 @@ def test_dinov2_and_siglip_hf_crosscheck(dev):
     assert rel_l2(out, torch.from_numpy(z["siglip_hs"])[2]) < 2e-2
 
 
+def test_projector_pools_up_like_the_reference_class(dev):
+    """merv_projector_forward with S < out_size (round 5: one-token-per-frame selections through MERV) against the reference class's
+    output on the same input and parameters (tests/golden/projector_upsample.npz)."""
+    from merv_amd.projector import AveragePooling3DProjector
+    z = np.load(G / "projector_upsample.npz")
+    for tag, T, C in (("s1", 16, 64), ("s2", 8, 32)):
+        proj = AveragePooling3DProjector(C, 128, output_frames=T, output_size=8, mlp_type="linear")
+        proj.load_state_dict({"projector.projector.weight": torch.from_numpy(z[f"{tag}_w"]),
+                              "projector.projector.bias": torch.from_numpy(z[f"{tag}_b"])})
+        out = proj(torch.from_numpy(z[f"{tag}_x"]).to(dev))
+        assert rel_l2(out, torch.from_numpy(z[f"{tag}_y"])) < 1e-2, tag
+
+
 def test_projector_and_fusion_reference_classes(dev):
     from merv_amd.projector import AveragePooling3DProjector, CrossAttentionAdapterLearnableQuery
     z = np.load(G / "projector_fusion.npz")

@@ -86,6 +86,20 @@ def test_projector_oracle_matches_reference_class():
     assert torch.allclose(y, torch.from_numpy(z["proj_full_y"]), atol=2e-5, rtol=1e-5)
 
 
+def test_projector_oracle_pools_up_like_the_reference_class():
+    """One token per frame (S = 1: class-token / averaged / pooled selections through MERV) and a 2 x 2 grid: the reference's
+    AveragePooling3DProjector pools UP to 8 x 8 (tools/make_goldens.py gen_projector_upsample); the oracle's explicit windows agree."""
+    z = np.load(G / "projector_upsample.npz")
+    assert O.adaptive_windows(1, 8) == [(0, 1)] * 8 and O.adaptive_windows(2, 8) == [(0, 1)] * 4 + [(1, 2)] * 4
+    for tag, S in (("s1", 1), ("s2", 2)):
+        x = torch.from_numpy(z[f"{tag}_x"])
+        B, T, N, Cc = x.shape
+        y = O.projector_forward(x.reshape(B, T * N, Cc), T, S, 8, torch.from_numpy(z[f"{tag}_w"]), torch.from_numpy(z[f"{tag}_b"]))
+        assert torch.allclose(y, torch.from_numpy(z[f"{tag}_y"]), atol=1e-5, rtol=1e-5)
+    y1 = torch.from_numpy(z["s1_y"]).reshape(2, 16, 64, -1)
+    assert torch.equal(y1, y1[:, :, :1].expand_as(y1))  # S = 1: the 64 output tokens of a frame are one row
+
+
 @pytest.mark.parametrize("tag", ["small", "e1", "wide"])
 def test_fusion_oracle_matches_reference_class(tag):
     z = np.load(G / "projector_fusion.npz")

@@ -186,6 +186,29 @@ def gen_projector_fusion():
 
 
 # ----------------------------------------------------------------------------------------------------------
+def gen_projector_upsample():
+    """The reference's AveragePooling3DProjector on ONE token per frame (the registry's class-token / averaged / pooled selections reach
+    MERV.forward as [B, T, 1, C], merv.py:576-585): AdaptiveAvgPool3d((T, 8, 8)) pools the 1 x 1 grid UP -- every output cell is that
+    token -- before the Linear. Pins the window rule for S < out_size (round 5: such ids run through MERV) on the reference class itself."""
+    _stub_timm()
+    nn_utils = _load("ref_nn_utils_up", REF / "merv/util/nn_utils.py")
+    torch.manual_seed(77)
+    out = {}
+    for tag, S, T, C, llm, B in (("s1", 1, 16, 64, 128, 2), ("s2", 2, 8, 32, 128, 1)):
+        proj = nn_utils.AveragePooling3DProjector(C, llm, output_frames=T, output_size=8, mlp_type="linear").eval()
+        x = torch.randn(B, T, S * S, C)
+        with torch.no_grad():
+            y = proj(x)
+        sd = proj.state_dict()
+        out[f"{tag}_x"] = x.numpy()
+        out[f"{tag}_w"] = sd["projector.projector.weight"].numpy()
+        out[f"{tag}_b"] = sd["projector.projector.bias"].numpy()
+        out[f"{tag}_y"] = y.numpy()
+    np.savez_compressed(OUT / "projector_upsample.npz", **out)
+    print("projector_upsample: ok", {k: v.shape for k, v in out.items() if k.endswith("_y")})
+
+
+# ----------------------------------------------------------------------------------------------------------
 def _load_languagebind():
     import transformers.models.clip.modeling_clip as mc
     if not hasattr(mc, "clip_loss"):
@@ -680,7 +703,8 @@ def gen_merv_forward():
 
 GENERATORS = {"frames": gen_frame_indices, "projfus": gen_projector_fusion, "lb": gen_languagebind, "vivit": gen_vivit,
               "hf": gen_hf_crosscheck, "prompts": gen_prompts, "preprocess": gen_preprocess,
-              "token_selection": gen_token_selection, "siglip_pool": gen_siglip_pool, "merv_forward": gen_merv_forward}
+              "token_selection": gen_token_selection, "siglip_pool": gen_siglip_pool, "merv_forward": gen_merv_forward,
+              "projector_upsample": gen_projector_upsample}
 
 
 def main(argv):
