@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
         const int L = std::max(20, (int)(chunk_s * 1e3 / (ms / 20)));
         for (int i = 0; i < (int)(2.0e3 / (ms / 20)); ++i) merv::launch_gemm(g, 0);  // >= 2 s of back-to-back launches on random data
         hipDeviceSynchronize();
-        std::vector<double> wall[NM], clk[NM], life[NM];
+        std::vector<double> wall[NM], clk[NM], life[NM], clk_k[NM], clk_e[NM], kshare[NM];
         std::vector<unsigned long long> hs(nblk * 8 * 16);
         for (int r = 0; r < rounds; ++r)
             for (int mi = 0; mi < NM; ++mi) {
@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
                 hipEventElapsedTime(&ms, e0, e1);
                 wall[m].push_back(ms * 1e3 / L);
                 hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost);
-                std::vector<double> c, lf;
+                std::vector<double> c, lf, ck, ce, ks;
                 for (size_t b = 0; b < nblk; ++b) {
                     unsigned long long c0 = ~0ull, c1 = 0, r0 = ~0ull, r1 = 0;
                     for (int w = 0; w < 8; ++w) {
@@ -136,9 +136,17 @@ int main(int argc, char** argv) {
                         c0 = std::min(c0, s[1]); c1 = std::max(c1, s[11]); r0 = std::min(r0, s[0]); r1 = std::max(r1, s[12]);
                     }
                     if (r1 > r0 && c1 > c0) { c.push_back((double)(c1 - c0) / (double)(r1 - r0) * 0.1); lf.push_back((double)(r1 - r0) / 100.0); }
+                    // per phase, wave 0 of the block: K-loop (entry .. K-loop end) and epilogue (K-loop end .. exit)
+                    const unsigned long long* s = &hs[(b * 8) * 16];
+                    if (s[13] > s[0] && s[12] > s[13] && s[4] > s[1] && s[11] > s[4]) {
+                        ck.push_back((double)(s[4] - s[1]) / (double)(s[13] - s[0]) * 0.1);
+                        ce.push_back((double)(s[11] - s[4]) / (double)(s[12] - s[13]) * 0.1);
+                        ks.push_back((double)(s[13] - s[0]) / (double)(s[12] - s[0]));
+                    }
                 }
                 clk[m].push_back(median(c));
                 life[m].push_back(median(lf));
+                clk_k[m].push_back(median(ck)); clk_e[m].push_back(median(ce)); kshare[m].push_back(median(ks));
             }
         const double flop = 2.0 * sh.M * sh.N * sh.K;
         printf("%s  {\"shape\": \"%s\", \"class\": \"%s\", \"M\": %d, \"N\": %d, \"K\": %d, \"eight_phase_rows\": %d, \"eight_phase_tiles\": %zu, \"launches_per_chunk\": %d, \"modes\": [\n",
@@ -148,9 +156,9 @@ int main(int argc, char** argv) {
         for (int m = 0; m < NM; ++m) {
             const double w = median(wall[m]);
             printf("    {\"mode\": \"%s\", \"wrap_a_bytes\": %d, \"wrap_w_bytes\": %d, \"a_blocked\": %d, \"us_per_launch_median\": %.2f, \"us_per_launch_min\": %.2f, \"tflops\": %.1f, "
-                   "\"clock_ghz\": %.3f, \"block_life_us\": %.2f, \"speedup_vs_product\": %.4f}%s\n",
+                   "\"clock_ghz\": %.3f, \"clock_ghz_kloop\": %.3f, \"clock_ghz_epilogue\": %.3f, \"kloop_share_of_block_life\": %.3f, \"block_life_us\": %.2f, \"speedup_vs_product\": %.4f}%s\n",
                    modes[m].name, modes[m].wrap_a, modes[m].wrap_w, modes[m].a_blocked, w, *std::min_element(wall[m].begin(), wall[m].end()), flop / w / 1e6, median(clk[m]),
-                   median(life[m]), base / w, m + 1 < NM ? "," : "");
+                   median(clk_k[m]), median(clk_e[m]), median(kshare[m]), median(life[m]), base / w, m + 1 < NM ? "," : "");
         }
         printf("  ]}");
         fflush(stdout);

@@ -29,7 +29,9 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;  // [block][8 waves][16]
             g_gemm_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = t__;                         \
     } while (0)
 #ifdef MERV_GEMM_STAMPS_LIGHT
-#define MERV_GSTAMP(k) do { if constexpr ((k) == 1 || (k) == 11) MERV_GSTAMP_(k, "s_memtime"); } while (0)
+// entry (1) / K-loop end (4) / exit (11) shader-clock stamps; with the real-time stamp taken at the same three points (0 / 13 / 12) the
+// clock of the K-loop and of the epilogue can be told apart
+#define MERV_GSTAMP(k) do { if constexpr ((k) == 1 || (k) == 11) MERV_GSTAMP_(k, "s_memtime"); if constexpr ((k) == 4) { MERV_GSTAMP_(4, "s_memtime"); MERV_GSTAMP_(13, "s_memrealtime"); } } while (0)
 #define MERV_PROBE_DRAIN_STORES() do { } while (0)
 #else
 #define MERV_GSTAMP(k) MERV_GSTAMP_(k, "s_memtime")
