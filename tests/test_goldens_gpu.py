@@ -63,7 +63,7 @@ def test_projector_pools_up_like_the_reference_class(dev):
     output on the same input and parameters (tests/golden/projector_upsample.npz)."""
     from merv_amd.projector import AveragePooling3DProjector
     z = np.load(G / "projector_upsample.npz")
-    for tag, T, C in (("s1", 16, 64), ("s2", 8, 32)):
+    for tag, T, C in (("s1", 16, 64), ("s2", 8, 64)):
         proj = AveragePooling3DProjector(C, 128, output_frames=T, output_size=8, mlp_type="linear")
         proj.load_state_dict({"projector.projector.weight": torch.from_numpy(z[f"{tag}_w"]),
                               "projector.projector.bias": torch.from_numpy(z[f"{tag}_b"])})

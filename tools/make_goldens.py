@@ -194,7 +194,7 @@ def gen_projector_upsample():
     nn_utils = _load("ref_nn_utils_up", REF / "merv/util/nn_utils.py")
     torch.manual_seed(77)
     out = {}
-    for tag, S, T, C, llm, B in (("s1", 1, 16, 64, 128, 2), ("s2", 2, 8, 32, 128, 1)):
+    for tag, S, T, C, llm, B in (("s1", 1, 16, 64, 128, 2), ("s2", 2, 8, 64, 128, 1)):
         proj = nn_utils.AveragePooling3DProjector(C, llm, output_frames=T, output_size=8, mlp_type="linear").eval()
         x = torch.randn(B, T, S * S, C)
         with torch.no_grad():
