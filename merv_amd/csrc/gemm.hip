@@ -39,6 +39,7 @@
 #define MERV_PROBE_W_ROW(r, p) (r)               // W row a DMA piece reads
 #define MERV_PROBE_A_OFFSET(r, p, es) ((size_t)(r) * (p).lda * (es))  // byte offset of A row r at k = 0 (eight-phase kernel)
 #define MERV_PROBE_A_KSTEP ROW_BYTES             // bytes between consecutive K-tiles of an A row
+#define MERV_PROBE_A_DMA_AUX 0                   // cache-policy bits of the eight-phase kernel's A pieces (2 = nt)
 #define MERV_PROBE_STORE_COND(p) true            // ANDed into the store predicate
 #define MERV_PROBE_STORE16(v, ptr) __builtin_nontemporal_store(v, ptr)  // the epilogue's 16-byte output stores (streaming: no L2 allocation)
 #define MERV_PROBE_SKIP_W_DMA(t) false           // eight-phase kernel: drop the W pieces of K-tile t
@@ -834,10 +835,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
+    auto dma_act = [&](const char* src, int lds_off) {  // the A (activation) pieces: cache-policy bits from the probe hook (product: 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, MERV_PROBE_A_DMA_AUX);
+    };
     const int a_kstep = MERV_PROBE_A_KSTEP;  // (product: the constant ROW_BYTES)
     auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma(a_src[sq][u] + t * a_kstep, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) dma_act(a_src[sq][u] + t * a_kstep, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
         if (MERV_PROBE_SKIP_W_DMA(t)) return;

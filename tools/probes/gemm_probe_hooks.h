@@ -10,6 +10,7 @@
 //                           operand footprint of the energy-bound probe (same MFMAs, same LDS traffic, fabric operand traffic -> ~0)
 //   MERV_ABL_PLAINSTORE     L2-allocating output stores instead of the streaming (nontemporal) ones
 //   MERV_ABL_ABLOCKED       the eight-phase kernel reads A in a K-tile-blocked layout (g_probe_a_blocked, runtime): contiguous 32 KB per (m-tile, K-tile)
+//   MERV_ABL_A_NT=bits      cache-policy bits on the eight-phase kernel's A pieces (2 = nt, 1 = sc0, 16 = sc1)
 //   MERV_ABL_NOSTORE        the whole epilogue, but nothing is stored (the condition is a runtime value: nothing is dead code)
 //   MERV_ABL_HALFDMA        W pieces after K-tile 0 are never loaded (is the K-loop load-path-bound?)
 //   MERV_ABL_NOEPI          prologue + K-loop + block turnover only
@@ -76,6 +77,12 @@ __device__ int g_probe_a_blocked = 0;
 #else
 #define MERV_PROBE_A_OFFSET(r, p, es) ((size_t)(r) * (p).lda * (es))
 #define MERV_PROBE_A_KSTEP 128
+#endif
+
+#ifdef MERV_ABL_A_NT  // the A pieces of the eight-phase kernel with the nt (streaming) cache policy: do they stop evicting the W panel from L2?
+#define MERV_PROBE_A_DMA_AUX MERV_ABL_A_NT
+#else
+#define MERV_PROBE_A_DMA_AUX 0
 #endif
 
 #ifdef MERV_ABL_NOSTORE
