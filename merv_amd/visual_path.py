@@ -20,6 +20,7 @@ projected [*, 64 rows per frame, llm] bf16 tokens to the rank that fuses the vid
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -81,6 +82,10 @@ class MervVisualPath:
         self.T_vis = self.tokens_out.pop()
         self.concurrent = concurrent_streams and len(self.encoders) > 1
         self.streams = _encoder_streams(self.device, len(self.encoders))
+        # cost rank of every encoder (0 = most FLOPs per video): the stream map below is written in ranks
+        order = sorted(range(len(self.specs)), key=lambda i: -self.specs[i].flops_per_video())
+        self._rank = {i: r for r, i in enumerate(order)}
+        self._stream_map_env = os.environ.get("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
         self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
         self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
         self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
@@ -177,6 +182,31 @@ class MervVisualPath:
         with torch.cuda.device(self.device):
             return self.fusion(list(projected), out=fb["out"], partial=fb["partial"], weights=fb["weights"])
 
+    def stream_map(self, batch: int) -> List[int]:
+        """Side stream of every encoder at this batch size. More concurrent kernel chains fill the tails of each other's launches, fewer
+        contend less for the per-XCD L2s (every chain streams its own weight panel and activations through them). Measured on the
+        merv-full four (round 5, EXPERIMENTS.md section 4; ms per step, one stream per encoder -> the map): 16 videos 114.4-117.2 -> 113.1-115.7
+        with the largest encoder alone and the other three back to back on ONE stream; 8 / 4 / 2 videos 59.8 / 31.0 / 17.1 -> 58.9 / 30.5 / 16.7
+        with the largest alone, the two middle ones sharing, the smallest alone; at one video every encoder keeps its own stream (10.0 ms
+        against 10.3 / 11.5: small launches need the company). Other encoder counts: one stream each."""
+        E = len(self.encoders)
+        m = self._stream_map_env
+        if not (m and len(m) == E):
+            m = ("0111" if batch >= 12 else "0112" if batch >= 2 else "0123") if E == 4 else "".join(str(i) for i in range(E))
+        return [int(m[self._rank[i]]) for i in range(E)]
+
+    def enqueue_order(self, batch: int) -> List[int]:
+        """Order in which the branches are enqueued (= executed, for encoders that share a stream): the largest encoder first (it has a
+        stream of its own), then the others from the SMALLEST up, so that the chain which ends the step alone is the second-largest encoder's
+        -- full-chip launches -- and the small encoders' under-filled launches run beside the largest's (16 videos, map 0111: 113.2-113.4 ms
+        with ranks 0 1 2 3, 112.6-112.9 with 0 3 2 1 or 0 2 3 1, 113.5-113.6 with 0 1 3 2 / 0 3 1 2). Probe hook MERV_ENCODER_ORDER: ranks."""
+        E = len(self.encoders)
+        o = os.environ.get("MERV_ENCODER_ORDER")
+        by_rank = sorted(range(E), key=lambda i: self._rank[i])
+        if o and sorted(o) == [str(r) for r in range(E)]:
+            return [by_rank[int(c)] for c in o]
+        return by_rank[:1] + by_rank[:0:-1]
+
     def _run_branches(self, pixels: Sequence[torch.Tensor], project: bool) -> List[torch.Tensor]:
         """The E independent branches (merv.py:563-566), each on its own stream when `concurrent`, event-joined on the
         current stream. project=True: a4-a9 (projected tokens); False: a4-a8 only (encoder tokens [B, T*S, C])."""
@@ -201,10 +231,12 @@ class MervVisualPath:
                     self._events[0] = (torch.cuda.Event(), [torch.cuda.Event() for _ in pixels])
                 start, dones = self._events[0]
             start.record(main)
-            for i, pix in enumerate(pixels):
-                st = self.streams[i]
+            smap = self.stream_map(pixels[0].shape[0])
+            outs = [None] * len(pixels)
+            for i in self.enqueue_order(pixels[0].shape[0]):  # encoders that share a stream run in this order
+                st = self.streams[smap[i]]
                 st.wait_event(start)
-                outs.append(branch(i, pix, st))
+                outs[i] = branch(i, pixels[i], st)
                 dones[i].record(st)
                 main.wait_event(dones[i])
         else:
