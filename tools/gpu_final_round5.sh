@@ -10,15 +10,17 @@ timeout 1200 python3 -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; echo "pyte
 timeout 300 python3 __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc $?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
 bash tools/gpu_profile_round.sh > $OUT/profile_round.log 2>&1; tail -5 $OUT/profile_round.log
 # same-box pair against the previous round's library, alternating
-for rep in 1 2; do for lib in ab/libmerv_hip_r4.so merv_amd/lib/libmerv_hip.so; do
-  MERV_HIP_LIB=$R/$lib timeout 400 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/ab_$(basename $lib .so)_$rep.json 2> $OUT/ab_$(basename $lib .so)_$rep.err
-done; done
+# (round 4 = its library AND its orchestration: one stream per encoder, enqueued in index order)
+for rep in 1 2 3; do
+  MERV_HIP_LIB=$R/ab/libmerv_hip_r4.so MERV_ENCODER_STREAM_MAP=0123 MERV_ENCODER_ORDER=0123 timeout 400 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/ab_libmerv_hip_r4_$rep.json 2> $OUT/ab_libmerv_hip_r4_$rep.err
+  MERV_HIP_LIB=$R/merv_amd/lib/libmerv_hip.so timeout 400 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/ab_libmerv_hip_$rep.json 2> $OUT/ab_libmerv_hip_$rep.err
+done
 python3 - $OUT <<'PY'
 import json, sys
 out = sys.argv[1]
 runs = []
-for rep in (1, 2):
-    for lib, tag in (("libmerv_hip_r4", "round-4 library (ab/libmerv_hip_r4.so: the tree at df1b89b)"), ("libmerv_hip", "round-5 library (merv_amd/lib/libmerv_hip.so)")):
+for rep in (1, 2, 3):
+    for lib, tag in (("libmerv_hip_r4", "round 4: ab/libmerv_hip_r4.so (the tree at df1b89b) + its orchestration (MERV_ENCODER_STREAM_MAP=0123 MERV_ENCODER_ORDER=0123: one stream per encoder, index order)"), ("libmerv_hip", "round 5: merv_amd/lib/libmerv_hip.so + the batch-dependent stream map")):
         try:
             d = json.loads(open(f"{out}/ab_{lib}_{rep}.json").read().strip().splitlines()[-1])
             runs.append({"library": tag, "rep": rep, "tokens_per_s": d["value"], "ms_per_step": d["ms_per_step"], "gemm_roofline_frac": d["roofline"]["frac"],
@@ -28,10 +30,11 @@ for rep in (1, 2):
             runs.append({"library": tag, "rep": rep, "error": str(e)})
 doc = {"what": "same-box pair: `bench.py --steps 20 --warmup 5 --no-cpu-baseline` with MERV_HIP_LIB pointing at the previous round's library and at this round's, "
                "alternating, one GPU session (boxes of the pool differ by +-3 %, so only this pair says whether a round moved the headline). Round 5 changed no kernel "
-               "of the visual path (gemm.hip / attention.hip / rowops.hip device code identical to round 4's apart from register renames): the pair is expected to tie.",
+               "of the visual path (gemm.hip / attention.hip / rowops.hip device code identical to round 4's apart from register renames); what differs is which encoders share a "
+               "stream and the order they are enqueued in (MervVisualPath.stream_map / enqueue_order), so ms_per_step moves and the one-stream roofline leg does not.",
        "runs": runs}
 json.dump(doc, open(f"{out}/ab_prev_round.json", "w"), indent=1)
-print(json.dumps([(r.get("library", "")[:9], r.get("ms_per_step"), r.get("gemm_roofline_frac"), r.get("e2e_gen_tok_s")) for r in runs]))
+print(json.dumps([(r.get("library", "")[:7], r.get("ms_per_step"), r.get("gemm_roofline_frac"), r.get("e2e_gen_tok_s")) for r in runs]))
 PY
 for B in 1 2 4 8 16; do
   timeout 300 python3 bench.py --batch $B --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-prof > $OUT/sweep_b$B.json 2> $OUT/sweep_b$B.err
