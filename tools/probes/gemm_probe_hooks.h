@@ -14,6 +14,7 @@
 //   MERV_ABL_NOSTORE        the whole epilogue, but nothing is stored (the condition is a runtime value: nothing is dead code)
 //   MERV_ABL_HALFDMA        W pieces after K-tile 0 are never loaded (is the K-loop load-path-bound?)
 //   MERV_ABL_NOEPI          prologue + K-loop + block turnover only
+//   MERV_ABL_QUAD_ORDER=n   issue order of the eight-phase kernel's 16 MFMAs per phase (correct results: same sums)
 //   MERV_ABL_REST=1|2       the remaining rows are not computed at all / an empty launch in their place
 #pragma once
 #define MERV_GEMM_PROBE_HOOKS 1
@@ -101,6 +102,12 @@ __device__ int g_probe_a_blocked = 0;
 #define MERV_PROBE_SKIP_W_DMA(t) ((t) > 0)
 #else
 #define MERV_PROBE_SKIP_W_DMA(t) false
+#endif
+
+#ifdef MERV_ABL_QUAD_ORDER  // issue order of the 16 MFMAs of a phase (product: 4; 0 = the order of rounds 2-5)
+#define MERV_PROBE_QUAD_ORDER MERV_ABL_QUAD_ORDER
+#else
+#define MERV_PROBE_QUAD_ORDER 4
 #endif
 
 #ifdef MERV_ABL_NOEPI
