@@ -282,8 +282,7 @@ int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, in
 
 /* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128 two-deep ring, 3: 256x128,
  * 4: 256x128 with staggered half-blocks, 6: 128x128 four-deep ring, 7: 256x256 eight-phase where the shape allows it;
- * second byte: tile-order group size, 0 = default; third byte: 0 = leave the eight-phase kernel's three-deep-A rule as it is,
- * k + 1 = mode k: 0 never, 1 always, 2 for N <= 1024 and K >= 2048, 3 for N <= 1024). */
+ * second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
 /* Tuning / test hook: the attention kernels' deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to
  * 2^thr before its softmax reference moves); 0 = exact running maximum, default 8, values outside [0, 64] restore the default. */

@@ -781,14 +781,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
 // time the trailing wave group has executed the same wait (rule "read a staged buffer one phase AFTER the wait that
 // retires it", one barrier more because of the stagger).
 // ---------------------------------------------------------------------------------------------------------
-//
-// A3 (round 5): the A (activation) tiles in a THREE-deep ring of 32 KB slots, the W tiles in the two-deep one: 3 x 32 + 2 x 32 KB =
-// all 160 KB of the CU's LDS. A's slot of tile t + 2 is the one tile t - 1 was read from, so it is free during the whole of tile t,
-// and the early / late recycling rule is only needed for W. A tile then issues nothing but tile t + 2's pieces,
-//   phase 1: DMA A-early(t+2)   phase 2: DMA A-late(t+2)   phase 3: DMA B-early(t+2)   phase 4: DMA B-late(t+2), wait vmcnt(8)
-// and the one wait of phase 4 retires exactly what tile t - 1 issued: every piece has at least a whole K-tile to arrive (the A pieces
-// 1.5-2), where the two-deep form gives the late quarters half a K-tile (they are requested in the tile that waits for them). For the
-// launches whose A rows come from beyond the L2 on every K-tile (few column tiles per row tile, deep K: proj, fc2).
 // Issue order of the 16 MFMAs of one phase of the eight-phase kernel: position x -> (k-half kk) << 3 | (W fragment ii) << 2 | (A fragment jj).
 // Every order gives the same bits (an accumulator takes k-half 0 before k-half 1); what differs is which operand registers an MFMA shares
 // with its predecessors, and on random operands that is ENERGY: a bare MFMA loop over this wave tile (tools/probes/mfma_hold.hip, no
@@ -818,7 +810,7 @@ constexpr int quad_order(int ord, int x) {
     return kk << 3 | ii << 2 | jj;
 }
 
-template <bool REMAP, int ACT, bool MX, int EPI, bool A3 = false>
+template <bool REMAP, int ACT, bool MX, int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // MX = true: the same schedule on MXFP8 operands (OCP e4m3 elements, one E8M0 scale per 32 elements of K,
     // v_mfma_scale_f32_16x16x128_f8f6f4: twice the bf16 MFMA rate and half the operand bytes). A K-tile is still 128
@@ -831,10 +823,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int ES = MX ? 1 : 2;                // bytes per operand element
     constexpr int BKE = ROW_BYTES / ES;           // elements of K per K-tile
     constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
-    static_assert(!A3 || !MX, "the three-deep A ring is a bf16 form (the MX scales would not fit beside it)");
-    // byte offset of W buffer b / of the A tile that goes with buffer b in the two-deep form (A3: A slots are runtime offsets k * A_BYTES)
-    auto w_base = [](int b) { return A3 ? 3 * A_BYTES + b * A_BYTES : b * BUF_BYTES + A_BYTES; };
-    constexpr int W_IN_BUF = A3 ? 0 : A_BYTES;  // two-deep form: W sits behind A inside each 64 KB buffer (kept in b_rd as before)
     constexpr bool DIRECT = gemm_direct_epilogue<ACT> && !MX;  // MX: the W block scales are laid out by (unpermuted) row fragment
     static_assert(!MX || EPI == EPI_GENERIC, "MXFP8 launches take the generic epilogue");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -882,15 +870,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, MERV_PROBE_A_DMA_AUX);
     };
     const int a_kstep = MERV_PROBE_A_KSTEP;  // (product: the constant ROW_BYTES)
-    auto dma_a = [&](int sq, int t, int buf) {  // A3: `buf` is the slot's byte offset
+    auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma_act(a_src[sq][u] + t * a_kstep, (A3 ? buf : buf * BUF_BYTES) + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) dma_act(a_src[sq][u] + t * a_kstep, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
     };
     auto dma_b = [&](int sq, int t, int buf) {
         if (MERV_PROBE_SKIP_W_DMA(t)) return;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            dma(b_src[sq][u] + t * ROW_BYTES, w_base(buf) + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
+            dma(b_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
     };
     // MX block scales, layout [K-tile][64-row group][lane = 16 * kblock + row % 16][(row % 64) / 16] bytes: waves 0-3
     // bring the A groups of this tile's 256 rows, waves 4-7 the W groups (256 B each, 4 B per lane)
@@ -914,7 +902,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 
     const int nkt = p.K / BKE;
     const int frow = lane & 15, fq = lane >> 4, sw = lane & 7;
-    const int a_rd = (wr * WTM + frow) * ROW_BYTES, b_rd = W_IN_BUF + (wc * WTN + frow) * ROW_BYTES;
+    const int a_rd = (wr * WTM + frow) * ROW_BYTES, b_rd = A_BYTES + (wc * WTN + frow) * ROW_BYTES;
     const int coff0 = ((0 + fq) ^ sw) * 16, coff1 = ((4 + fq) ^ sw) * 16;
 
     // prologue: all of tile 0 and the early quarters of tile 1 are requested (the launcher guarantees nkt >= 4), but the first
@@ -923,14 +911,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // is bandwidth-bound and half the bytes arrive in about half the time
     dma_s(0, 0);
     dma_a(0, 0, 0); dma_b(0, 0, 0); dma_b(1, 0, 0); dma_a(1, 0, 0);
-    if constexpr (A3) {  // all of tile 1 as well (slot 1): 16 pieces per wave in flight
-        dma_a(0, 1, A_BYTES); dma_b(0, 1, 1); dma_b(1, 1, 1); dma_a(1, 1, A_BYTES);
-    } else {
-        dma_a(0, 1, 1); dma_b(0, 1, 1);
-    }
+    dma_a(0, 1, 1); dma_b(0, 1, 1);
     acc_init<EPI, DIRECT>(p, acc, lane, n0 + wc * WTN);  // EPI_PLAIN / EPI_LS: the accumulators start at the bias (scalar loads)
     MERV_GSTAMP(2);  // prologue DMAs issued
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A3 ? 12 : 8) : "memory");
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     MERV_GSTAMP(3);  // tile 0's early quarters have landed: first phase released
     if (wr == 1) asm volatile("s_barrier" ::: "memory");  // trailing group: one barrier behind from here on
@@ -949,7 +933,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     auto read_a = [&](int buf, int mh) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const char* base = smem + (A3 ? buf : buf * BUF_BYTES) + a_rd + (mh * 4 + jj) * 16 * ROW_BYTES;
+            const char* base = smem + buf * BUF_BYTES + a_rd + (mh * 4 + jj) * 16 * ROW_BYTES;
             if constexpr (MX) {
                 af8[jj] = load32(base);
             } else {
@@ -961,7 +945,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     auto read_w = [&](int buf, int nh) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii) {
-            const char* base = smem + (w_base(buf) - W_IN_BUF) + b_rd + (nh * 2 + ii) * 16 * ROW_BYTES;
+            const char* base = smem + buf * BUF_BYTES + b_rd + (nh * 2 + ii) * 16 * ROW_BYTES;
             if constexpr (MX) {
                 wf8[nh][ii] = load32(base);
             } else {
@@ -1056,60 +1040,39 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // wave's queue then holds, youngest last: [the quarter wanted][the other late quarter or nothing][tile 1: A-early, B-early,
     // (MX scales), B-late, (A-late)] -> all but the 8 (MX: 9) youngest), one phase ahead of the read as the ordering rule asks.
     using I2 = std::integral_constant<int, 2>;
-    // A3: `ac` = byte offset of the A slot tile t is read from, `an` = of the slot tile t + 2 goes to (the one tile t - 1 left)
-    auto k_tile = [&](int t, auto buf_tag, auto mode_tag, auto first_tag, int ac, int an) {
+    auto k_tile = [&](int t, auto buf_tag, auto mode_tag, auto first_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool has1 = MODE <= 1, has2 = MODE == 0;
         static_assert(!FIRST || MODE == 0, "the first tile always has two successors");
-        const int ab = A3 ? ac : BUF;  // what read_a / dma_a take for "this tile's A"
         // phase 1
         read_scales(BUF);
         read_w(BUF, 0);
         __builtin_amdgcn_sched_barrier(0);
-        read_a(ab, 0);
-        if constexpr (A3) {
-            if constexpr (has2) dma_a(0, t + 2, an);
-            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // tile 0's B-late: all but [A-late(0), tile 1, A-early(2)]
-        } else {
-            if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
-            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
-        }
+        read_a(BUF, 0);
+        if constexpr (has1) { dma_s(t + 1, BUF ^ 1); dma_b(1, t + 1, BUF ^ 1); }
+        if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I0{});
         MERV_PH_DONE();
         // phase 2
         read_w(BUF, 1);
-        if constexpr (A3) {
-            if constexpr (has2) dma_a(1, t + 2, an);
-            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // tile 0's A-late: all but [tile 1, A(2)]
-        } else {
-            if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
-            if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
-        }
+        if constexpr (has1) dma_a(1, t + 1, BUF ^ 1);
+        if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MX ? 9 : 8) : "memory");
         MERV_PH_LOADED();
         quadrant(I0{}, I1{});
         MERV_PH_DONE();
         // phase 3
-        read_a(ab, 1);
-        if constexpr (A3) {
-            if constexpr (has2) dma_b(0, t + 2, BUF);
-        } else {
-            if constexpr (has2) dma_a(0, t + 2, BUF);
-        }
+        read_a(BUF, 1);
+        if constexpr (has2) dma_a(0, t + 2, BUF);
         MERV_PH_LOADED();
         quadrant(I1{}, I1{});
         MERV_PH_DONE();
         // phase 4
         if constexpr (has2) {
-            if constexpr (A3) {
-                dma_b(1, t + 2, BUF);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything tile t - 1 requested (= tile t + 1) has landed
-            } else {
-                dma_b(0, t + 2, BUF);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            }
+            dma_b(0, t + 2, BUF);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else if constexpr (has1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1117,18 +1080,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         quadrant(I1{}, I0{});
         MERV_PH_DONE();
     };
-    // A slots (A3): tile t in slot t % 3, as byte offsets rotated at run time (the W buffer stays a compile-time t % 2)
-    int a0 = 0, a1 = A_BYTES, a2 = 2 * A_BYTES;
-    auto rot = [&]() { const int x = a0; a0 = a1; a1 = a2; a2 = x; };
-    k_tile(0, I0{}, I0{}, std::true_type{}, a0, a2); rot();
-    k_tile(1, I1{}, I0{}, std::false_type{}, a0, a2); rot();
+    k_tile(0, I0{}, I0{}, std::true_type{});
+    k_tile(1, I1{}, I0{}, std::false_type{});
     int t = 2;
     for (; t + 2 < nkt; t += 2) {
-        k_tile(t, I0{}, I0{}, std::false_type{}, a0, a2); rot();
-        k_tile(t + 1, I1{}, I0{}, std::false_type{}, a0, a2); rot();
+        k_tile(t, I0{}, I0{}, std::false_type{});
+        k_tile(t + 1, I1{}, I0{}, std::false_type{});
     }
-    k_tile(t, I0{}, I1{}, std::false_type{}, a0, a2); rot();
-    k_tile(t + 1, I1{}, I2{}, std::false_type{}, a0, a2);
+    k_tile(t, I0{}, I1{}, std::false_type{});
+    k_tile(t + 1, I1{}, I2{}, std::false_type{});
 #undef MERV_PH_LOADED
 #undef MERV_PH_DONE
 #undef MERV_MX_MMA
@@ -1169,33 +1129,15 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
     return e;
 }
 
-template <bool REMAP, int ACT, int EPI, bool MX = false, bool A3 = false>
-hipError_t launch_8phase3(const GemmArgs& a, hipStream_t s) {
-    constexpr int LDS = A3 ? 5 * 256 * ROW_BYTES : 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales); A3: 160 KB
-    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI, A3>;
+template <bool REMAP, int ACT, int EPI, bool MX = false>
+hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
+    constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
+    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + 255) / 256, tilesN = a.N / 256;
     hipLaunchKernelGGL(kern, dim3(tilesM * tilesN), dim3(512), LDS, s, a);
     return hipGetLastError();
-}
-// Which launches take the three-deep A ring (MERV_GEMM_A3: 0 none, 1 all, 2 N <= 1024 and K >= 2048, 3 N <= 1024; A/B hook)
-int g_gemm_a3 = -1;
-inline bool use_a3(const GemmArgs& a) {
-    if (g_gemm_a3 < 0) g_gemm_a3 = getenv("MERV_GEMM_A3") ? atoi(getenv("MERV_GEMM_A3")) : 0;
-    switch (g_gemm_a3) {
-        case 1: return true;
-        case 2: return a.N <= 1024 && a.K >= 2048;
-        case 3: return a.N <= 1024;
-        default: return false;
-    }
-}
-template <bool REMAP, int ACT, int EPI, bool MX = false>
-hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
-    if constexpr (!REMAP && !MX) {
-        if (use_a3(a)) return launch_8phase3<REMAP, ACT, EPI, MX, true>(a, s);
-    }
-    return launch_8phase3<REMAP, ACT, EPI, MX, false>(a, s);
 }
 // The epilogue mode of a launch (see EPI_*). Row remapping (patch embedding) and activations never come with a LayerScale in the
 // encoder stack: those combinations exist only in generic form.
@@ -1342,11 +1284,7 @@ inline bool row_add_ok(const GemmArgs& a) {
 
 }  // namespace
 
-void set_gemm_variant(int v) {
-    g_gemm_variant = v & 0xff;
-    g_gemm_group_m = (v >> 8) & 0xff;
-    if ((v >> 16) & 0xff) g_gemm_a3 = ((v >> 16) & 0xff) - 1;  // third byte: 0 leaves the three-deep-A rule as it is, k + 1 sets mode k
-}
+void set_gemm_variant(int v) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
 
 // Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc % 8 == 0.
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {

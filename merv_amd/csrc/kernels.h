@@ -67,8 +67,7 @@ hipError_t launch_mx_quantize(const MxQuantArgs& a, hipStream_t s);
 size_t mx_scale_bytes(int rows, int K);
 void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128 2-deep ring, 3: 256x128, 4: 256x128 staggered, 6: 128x128 4-deep ring,
                                // 7: 256x256 eight-phase (2 and 5 were the retired two-stage 256x256 forms);
-                               // second byte: tile-order group size override (tuning / tests); third byte: 0 leaves the three-deep-A
-                               // rule of the eight-phase kernel as it is, k + 1 sets mode k (0 never, 1 always, 2 N <= 1024 and K >= 2048, 3 N <= 1024)
+                               // second byte: tile-order group size override (tuning / tests)
 
 // Row LayerNorm (fp32 statistics), optional fused "x += add[(row / add_div) % add_mod]" written back in place
 // (LanguageBind temporal embedding, modeling_video.py:138-141).
