@@ -844,9 +844,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     const int in_grp = id - grp * per_group;
     const int m0 = (first_m + in_grp % gsz) * BM, n0 = (in_grp / gsz) * BN;
 
-    // per-lane DMA sources at kt = 0; [s] = early / late quarter, [u] = this wave's two 8-row pieces of the quarter
+    // DMA sources; [s] = early / late quarter, [u] = this wave's two 8-row pieces of the quarter. SADDR form (round 5): the tile's first
+    // row at k = 0 is a wave-uniform pointer (SGPRs, advanced by scalar adds) and each piece a 32-bit per-lane byte offset computed
+    // once (row inside the tile, clamped; source-side swizzle), so the instruction is global_load_lds_dwordx4 v_off, s[base:base+1] and
+    // the K-loop carries NO per-piece 64-bit vector address arithmetic (16 v_lshl_add_u64 per wave and K-tile in the pointer form,
+    // issued right in front of the pieces they feed). The probe builds keep the per-lane pointer form (their hooks rewrite rows).
+#ifndef MERV_GEMM_SADDR
+#ifdef MERV_GEMM_PROBE_HOOKS
+#define MERV_GEMM_SADDR 0
+#else
+#define MERV_GEMM_SADDR 1
+#endif
+#endif
+    constexpr bool SADDR = MERV_GEMM_SADDR != 0;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     const char* a_src[2][2];
     const char* b_src[2][2];
+    uint32_t a_off[2][2], b_off[2][2];
+    const char* const a_tile = (const char*)p.A + (size_t)m0 * p.lda * ES;  // wave-uniform
+    const char* const b_tile = (const char*)p.W + (size_t)n0 * p.ldw * ES;
     const int r8 = lane >> 3, sw8 = ((lane & 7) ^ r8) * 16;  // source-side swizzle, in bytes
 #pragma unroll
     for (int sq = 0; sq < 2; ++sq)
@@ -854,12 +870,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         for (int u = 0; u < 2; ++u) {
             int grow = m0 + u * 128 + sq * 64 + wave * 8 + r8;
             grow = grow < p.M - 1 ? grow : p.M - 1;  // rows past M re-read the last valid row (never stored)
-            grow = MERV_PROBE_A_ROW(grow, p);
-            a_src[sq][u] = (const char*)p.A + MERV_PROBE_A_OFFSET(grow, p, ES) + sw8;
             // LDS row slot ((wave >> 2) + 2 u) * 64 + sq * 32 + (wave & 3) * 8 + r8; DIRECT: it receives the permuted W row
             const int s32 = (wave & 3) * 8 + r8;
-            const int nrow = MERV_PROBE_W_ROW(n0 + ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32), p);
-            b_src[sq][u] = (const char*)p.W + (size_t)nrow * p.ldw * ES + sw8;
+            const int nrel = ((wave >> 2) + 2 * u) * 64 + sq * 32 + (DIRECT ? w_row_perm32(s32) : s32);
+            if constexpr (SADDR) {
+                a_off[sq][u] = (uint32_t)(grow - m0) * (uint32_t)(p.lda * ES) + sw8;  // < 256 rows x row pitch: 32 bits (the launcher checks)
+                b_off[sq][u] = (uint32_t)nrel * (uint32_t)(p.ldw * ES) + sw8;
+            } else {
+                grow = MERV_PROBE_A_ROW(grow, p);
+                a_src[sq][u] = (const char*)p.A + MERV_PROBE_A_OFFSET(grow, p, ES) + sw8;
+                const int nrow = MERV_PROBE_W_ROW(n0 + nrel, p);
+                b_src[sq][u] = (const char*)p.W + (size_t)nrow * p.ldw * ES + sw8;
+            }
         }
     auto dma = [&](const char* src, int lds_off) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -869,16 +891,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, MERV_PROBE_A_DMA_AUX);
     };
+    // the SADDR form goes through inline asm (hipcc selects the vector-address form for the builtin whatever the pointer is made of):
+    // M0 = the piece's LDS byte address, written and declared clobbered inside the statement. The explicit vmcnt waits of the K-loop
+    // are the only ordering these pieces have ever had (the compiler never waits for a DMA it issued through the builtin either);
+    // the epilogue starts behind a vmcnt(0).
+    auto dma_saddr = [&](const char* sbase, uint32_t voff, int lds_off) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base + lds_off) : "memory");
+    };
     const int a_kstep = MERV_PROBE_A_KSTEP;  // (product: the constant ROW_BYTES)
     auto dma_a = [&](int sq, int t, int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) dma_act(a_src[sq][u] + t * a_kstep, buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024);
+        for (int u = 0; u < 2; ++u) {
+            const int dst = buf * BUF_BYTES + (u * 16 + sq * 8 + wave) * 1024;
+            if constexpr (SADDR) dma_saddr(a_tile + t * ROW_BYTES, a_off[sq][u], dst);
+            else dma_act(a_src[sq][u] + t * a_kstep, dst);
+        }
     };
     auto dma_b = [&](int sq, int t, int buf) {
         if (MERV_PROBE_SKIP_W_DMA(t)) return;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-            dma(b_src[sq][u] + t * ROW_BYTES, buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024);
+        for (int u = 0; u < 2; ++u) {
+            const int dst = buf * BUF_BYTES + A_BYTES + ((((wave >> 2) + 2 * u) * 8 + sq * 4 + (wave & 3))) * 1024;
+            if constexpr (SADDR) dma_saddr(b_tile + t * ROW_BYTES, b_off[sq][u], dst);
+            else dma(b_src[sq][u] + t * ROW_BYTES, dst);
+        }
     };
     // MX block scales, layout [K-tile][64-row group][lane = 16 * kblock + row % 16][(row % 64) / 16] bytes: waves 0-3
     // bring the A groups of this tile's 256 rows, waves 4-7 the W groups (256 B each, 4 B per lane)
@@ -893,9 +929,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         s_stride = (size_t)gtot * 256;
     }
     auto dma_s = [&](int t, int buf) {
-        if constexpr (MX)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_base + t * s_stride + (size_t)(uint32_t)(lane * 4)),
-                                             (__attribute__((address_space(3))) void*)(smem + SC_BASE + buf * 2048 + wave * 256), 4, 0, 0);
+        if constexpr (MX) {
+            if constexpr (SADDR)  // (no builtin DMA beside the asm ones: hipcc's own M0 writes must not meet M0 writes it cannot see)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)(lane * 4)), "s"(s_base + t * s_stride),
+                             "s"(lds_base + SC_BASE + buf * 2048 + wave * 256) : "memory");
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_base + t * s_stride + (size_t)(uint32_t)(lane * 4)),
+                                                 (__attribute__((address_space(3))) void*)(smem + SC_BASE + buf * 2048 + wave * 256), 4, 0, 0);
+        }
     };
 
     f32x4 acc[NI][MI];
@@ -1296,6 +1337,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if ((a.lda | a.ldw | a.ldc) % 8 != 0) return hipErrorInvalidValue;
     if (a.res && a.ldres % 8 != 0) return hipErrorInvalidValue;
     if (!row_add_ok(a)) return hipErrorInvalidValue;
+    if ((double)a.lda * 512 >= 4294967296.0 || (double)a.ldw * 512 >= 4294967296.0) return hipErrorInvalidValue;  // a tile's DMA piece offsets are 32-bit
     {   // the epilogue keeps element offsets in 32 bits
         const double rows_out = a.out_group > 0 ? ((double)(a.M / a.out_group) + 1) * a.out_stride + a.out_off : (double)a.M;
         if (rows_out * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
