@@ -518,7 +518,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{});
         tile_body(ntiles - 1, std::integral_constant<int, 2>{});
     } else {
-        for (int t = 0; t < ntiles; ++t) tile_body(t, std::integral_constant<int, 0>{});
+        // every tile but the last is a full one, known at compile time: its body has no tail / half-tile branches, so hipcc keeps the two
+        // query tiles' score chains interleaved and reads each K fragment once for both (with the run-time form every 32-key half sat
+        // behind a branch: fragments re-read per query tile, each read waited for right in front of its MFMA)
+        for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{});
+        tile_body(ntiles - 1, std::integral_constant<int, 0>{});
     }
     MERV_STAMP(30);
 
