@@ -328,7 +328,7 @@ int merv_prof_read(int32_t cls, double *total_ms, int64_t *launches, double *flo
  *  merv_decode_gemv        nn.Linear at M = 1: y[N] = bf16(W[N,K] x[K]) (+ res[N]); with W2: y = silu(bf16(W x)) * bf16(W2 x)
  *                          (LlamaMLP's act_fn(gate_proj(x)) * up_proj(x)); y32 != NULL: fp32 output instead (logits);
  *                          norm_w != NULL: the RMSNorm of the input fused in (x is the raw residual stream; bit-identical to
- *                          merv_decode_rmsnorm followed by the plain call)
+ *                          merv_decode_rmsnorm followed by the plain call; K <= 16384)
  *  merv_decode_rope_cache  apply_rotary_pos_emb at position *pos (device int64) on q [H*hd] -> q_out and k [Hkv*hd] -> k_cache[:, *pos],
  *                          v -> v_cache[:, *pos]; caches [Hkv, max_len, hd], cos / sin tables [max_len, hd] bf16
  *  merv_decode_attention   out[H*hd] = softmax(q K^T * scale) V over cache positions 0..*pos (GQA: kv head = h / (H/Hkv)),

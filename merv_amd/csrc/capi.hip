@@ -821,6 +821,7 @@ extern "C" int merv_decode_gemv(const void* W, const void* W2, const void* x, co
     MERV_CHECK(W && x && (y || y32), "merv_decode_gemv: null argument");
     MERV_CHECK(N > 0 && K > 0 && K % 8 == 0, "merv_decode_gemv: N > 0 and K % 8 == 0 required");
     MERV_CHECK(!(W2 && res), "merv_decode_gemv: the gated form takes no residual");
+    MERV_CHECK(!norm_w || K <= 16384, "merv_decode_gemv: the fused RMSNorm takes K <= 16384 (call merv_decode_rmsnorm first for a wider input)");
     MERV_CHECK(((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0 && (!W2 || ((uintptr_t)W2 & 15) == 0), "merv_decode_gemv: 16-byte alignment required");
     DecodeGemvArgs a{};
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.x = (const bf16_t*)x; a.res = (const bf16_t*)res; a.y = (bf16_t*)y; a.y32 = y32;
@@ -839,6 +840,7 @@ extern "C" int merv_decode_gemv3_bias(const void* Wa, const void* Wb, const void
                                       const void* bias_a, const void* bias_b, const void* bias_c, void* stream_) {
     MERV_STREAM_DEVICE(stream_);
     MERV_CHECK(Wa && Wb && Wc && x && ya && yb && yc, "merv_decode_gemv3: null argument");
+    MERV_CHECK(!norm_w || K <= 16384, "merv_decode_gemv3: the fused RMSNorm takes K <= 16384");
     MERV_CHECK(Na > 0 && Nb > 0 && Nc > 0 && Na % 2 == 0 && Nb % 2 == 0 && Nc % 2 == 0 && K > 0 && K % 8 == 0,
                "merv_decode_gemv3: even row counts and K % 8 == 0 required");
     DecodeGemvArgs a{};

@@ -149,14 +149,20 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(DecodeRmsArgs p, const
 
 // ---- GEMV: W [N, K] bf16 row-major streamed once; each wave owns ROWS output rows, lanes stride K in 16-byte chunks ----
 constexpr int GEMV_WAVES = 4;  // waves per block
+constexpr int GEMV_XN_CHUNKS = 2048;  // fused norm: the block's normalised input as an LDS image of 16-byte chunks (32 KB: K <= 16384)
 struct GemvLds {
     float norm_part[GEMV_WAVES];
 };
 
 // NW_MATS 1: y = W x (+ res); 2: y = silu(Wg x) * (Wu x); NORM: RMSNorm of x fused in; GEMV_ROWS: output rows per wave (the x chunk
 // is reused across them). `block`: this workgroup's index.
+// Fused norm (round 5): the BLOCK normalises x once -- thread t the chunks t + 256 i it already holds for its share of mean(x^2) --
+// into an LDS image, and every wave multiplies from that image. Until round 4 each wave normalised every chunk it met (two multiplies and
+// two bf16 roundings per element: ~80 VALU instructions per chunk against 16-32 of multiply-add for the wave's rows, and two more global
+// loads per chunk): the q / k / v launch ran 20.3 us against 17.0 for the same bytes without a norm. Same values (the formula and its
+// rounding points are unchanged), same accumulation order: same bits.
 template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS>
-MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
+MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x4* xn_lds) {  // xn_lds (NORM): K / 8 chunks of LDS
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
     int n0 = (block * GEMV_WAVES + wave) * GEMV_ROWS;
@@ -169,7 +175,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
         }
     }
     static_assert(GEMV_WAVES == 4, "the fused norm splits the row's sum of squares over the block's four waves");
-    // a wave past the last row still takes part in the fused norm's block-wide reduction (and then leaves)
+    // a wave past the last row still takes part in the fused norm's block-wide work (and then leaves)
     const bool idle = n0 >= p.N;
     if (idle && !NORM) return;
     const int nchunk = p.K >> 3;
@@ -185,11 +191,11 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
         wrow[0][r] = p.W + (size_t)n * p.K;
         if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
     }
-    // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and the x / norm-weight chunks they meet) are in
+    // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and, without a norm, the x chunks they meet) are in
     // flight per lane before the first use. Every trip is a full batch: chunks past the row's end are clamped to a valid
     // address and meet x = 0 (a remainder loop of single loads costs one memory round trip per iteration: 3 us of the
     // K = 11008 launch).
-    u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN], nv[NORM ? UN : 1];
+    u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN];
     auto issue_w = [&](int c) {
         c = c < nchunk ? c : 0;  // (rows shorter than 64 chunks: the lanes past the end load a valid chunk and multiply nothing)
 #pragma unroll
@@ -201,44 +207,74 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
                 for (int r = 0; r < GEMV_ROWS; ++r) wv[m][r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m][r] + cu * 8));
         }
     };
-    auto issue_x = [&](int c) {
-        c = c < nchunk ? c : 0;
+    auto issue_x = [&](int c) {  // (NORM: the chunks come from the LDS image at their use)
+        if constexpr (!NORM) {
+            c = c < nchunk ? c : 0;
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
-            xv[u] = *(const u32x4*)(p.x + cu * 8);
-            if constexpr (NORM) nv[u] = *(const u32x4*)(p.norm_w + cu * 8);
+            for (int u = 0; u < UN; ++u) {
+                const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+                xv[u] = *(const u32x4*)(p.x + cu * 8);
+            }
         }
     };
-    // fused RMSNorm: the BLOCK reduces mean(x^2) over the whole input once (8 KB, L2-resident; a quarter per wave) and every wave
-    // normalises the chunks it multiplies. The norm's chunks are requested FIRST (vmcnt is in order: they return first) and the
-    // whole first trip before anything waits for them.
+    // fused RMSNorm: the BLOCK reduces mean(x^2) over the whole input once (8 KB, L2-resident; a quarter per wave) and normalises it
+    // once. The norm's chunks are requested FIRST (vmcnt is in order: they return first) and the whole first weight trip before
+    // anything waits for them.
     int c = lane;
-    u32x4 nx[4];
-    if constexpr (NORM) sumsq_request(p.x, nchunk, lane, wave, nx);
+    u32x4 nx[4], nw[4];
+    if constexpr (NORM) {
+        sumsq_request(p.x, nchunk, lane, wave, nx);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // the norm weight of the same chunks (thread t: chunks t + 256 i)
+            const int cc = lane + 64 * wave + 256 * i;
+            nw[i] = cc < nchunk ? *(const u32x4*)(p.norm_w + cc * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     // unconditional (idle waves of the last block re-read a valid row, lanes past a short row's end a valid chunk): behind a
     // branch hipcc's waitcnt pass joins the two paths and waits vmcnt(0) for the norm's chunks, i.e. for the whole weight trip
     issue_w(c);
     issue_x(c);
     __builtin_amdgcn_sched_barrier(0);  // the whole first trip is requested before anything waits for the norm's chunks
-    float rstd = 0.f;
     if constexpr (NORM) {
         const float part = sumsq_finish(p.x, nchunk, lane, wave, nx);  // (K <= 8192: no load inside)
         if (lane == 0) lds.norm_part[wave] = part;
         __syncthreads();
+        const float rstd = rsqrtf((((lds.norm_part[0] + lds.norm_part[1]) + lds.norm_part[2]) + lds.norm_part[3]) / (float)p.K + p.norm_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = lane + 64 * wave + 256 * i;
+            if (cc < nchunk) {
+                float xf[8], wn[8];
+                unpack8f(nx[i], xf);
+                unpack8f(nw[i], wn);
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)  // weight * hidden.to(bf16): two roundings, as the module (exact as bf16: the image keeps the values)
+                    o[q] = pack2bf(wn[2 * q] * round_bf(xf[2 * q] * rstd), wn[2 * q + 1] * round_bf(xf[2 * q + 1] * rstd));
+                xn_lds[cc] = o;
+            }
+        }
+        for (int cc = threadIdx.x + 1024; cc < nchunk; cc += 256) {  // K > 8192: the chunks sumsq_finish re-read, once more
+            float xf[8], wn[8];
+            unpack8f(*(const u32x4*)(p.x + cc * 8), xf);
+            unpack8f(*(const u32x4*)(p.norm_w + cc * 8), wn);
+            u32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = pack2bf(wn[2 * q] * round_bf(xf[2 * q] * rstd), wn[2 * q + 1] * round_bf(xf[2 * q + 1] * rstd));
+            xn_lds[cc] = o;
+        }
+        __syncthreads();
         if (idle) return;
-        rstd = rsqrtf((((lds.norm_part[0] + lds.norm_part[1]) + lds.norm_part[2]) + lds.norm_part[3]) / (float)p.K + p.norm_eps);
     }
     for (; c < nchunk; c += 64 * UN) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             float xf[8];
-            unpack8f(xv[u], xf);
             if constexpr (NORM) {
-                float wn[8];
-                unpack8f(nv[u], wn);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xf[j] = round_bf(wn[j] * round_bf(xf[j] * rstd));
+                const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+                unpack8f(xn_lds[cu], xf);
+            } else {
+                unpack8f(xv[u], xf);
             }
             if (c + 64 * u >= nchunk) {
 #pragma unroll
@@ -281,8 +317,11 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds) {
 
 template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
+    // NORM: the normalised input's image, dynamic LDS sized by the launcher (2 K bytes: 8 KB at K = 4096 -- a fixed 32 KB image halved
+    // the resident blocks and cost the q / k / v launch 1.5 us)
+    extern __shared__ __attribute__((aligned(16))) char gemv_dyn_lds[];
     __shared__ GemvLds lds;
-    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds);
+    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds, (u32x4*)gemv_dyn_lds);
 }
 
 // ---- rotary embedding of q and k at the current position + cache update ----
@@ -833,16 +872,16 @@ hipError_t launch_add_rmsnorm(const DecodeRmsArgs& a, const bf16_t* delta, hipSt
     return hipGetLastError();
 }
 
-template <int ROWS, int UN>
+template <int ROWS, int UN, int UN_PAIR = (UN > 4 ? 4 : UN)>
 static hipError_t launch_gemv_cfg(const DecodeGemvArgs& a, hipStream_t s) {
     const int rows_per_block = ROWS * GEMV_WAVES;
     dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
     const dim3 blk(GEMV_WAVES * 64);
     if (a.W2) {
-        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, (UN > 4 ? 4 : UN), true, ROWS>), grid, blk, 0, s, a);
-        else hipLaunchKernelGGL((gemv_kernel<2, (UN > 4 ? 4 : UN), false, ROWS>), grid, blk, 0, s, a);
+        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, true, ROWS>), grid, blk, 2 * a.K, s, a);
+        else hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, false, ROWS>), grid, blk, 0, s, a);
     } else if (a.norm_w) {
-        hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS>), grid, blk, 0, s, a);
+        hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS>), grid, blk, 2 * a.K, s, a);
     } else {
         hipLaunchKernelGGL((gemv_kernel<1, UN, false, ROWS>), grid, blk, 0, s, a);
     }
@@ -851,27 +890,35 @@ static hipError_t launch_gemv_cfg(const DecodeGemvArgs& a, hipStream_t s) {
 
 hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     if (a.N <= 0 || a.K <= 0 || a.K % 8 != 0) return hipErrorInvalidValue;
+    if (a.norm_w && a.K > 8 * GEMV_XN_CHUNKS) return hipErrorInvalidValue;  // the fused norm keeps the normalised input in LDS (32 KB)
     if (a.Nb > 0 || a.Nc > 0) {
         if (a.W2 || a.res || a.y32 || a.N % 2 || a.Nb % 2 || a.Nc % 2 || (a.Nb > 0 && (!a.Wb || !a.yb)) ||
             (a.Nc > 0 && (!a.Wc || !a.yc || a.Nb <= 0)))
             return hipErrorInvalidValue;
     }
-    // UN (chunks per lane per trip) at two rows per wave, step time with Llama-2-7B geometry on MI355X: 4: 3.24 ms, 2: 3.26 ms,
-    // 8: 4.60 ms (284 registers with the norm arrays live); the norm is a template flag: 3.21 ms.
-    // Rows per wave / unroll for the plain projections (o_proj, down_proj: one matrix, no fused norm, 4096 rows): one row per wave
-    // with the whole 16-byte-chunk batch of a trip doubled (1 x 8) keeps the same 8 loads per lane in flight on twice the waves:
-    // o_proj 7.9 -> 7.8 us, down_proj 20.0 -> 18.6 (tools/probes/decode_kernels.py, MERV_GEMV_CFG sweep). With the RMSNorm fused
-    // in (q / k / v) every wave reduces mean(x^2) itself, so halving the rows per wave doubles that work: 22.1 -> 29.8 us; those
-    // launches and the gate / up pair stay at two rows per wave.
-    static const char* cfg = getenv("MERV_GEMV_CFG");  // tuning hook: "<rows><un>", e.g. "14", "18", "24"
+    // Rows per wave x 16-byte chunks per lane and trip (every configuration multiplies a lane's chunks in the same order: same bits).
+    // Rounds 1-4 (tools/probes/decode_kernels.py, MERV_GEMV_CFG sweeps): 2 x 4 everywhere, then 1 x 8 for the plain projections of <= 16384
+    // rows (o_proj 7.9 -> 7.8 us, down_proj 20.0 -> 18.6) -- with the RMSNorm fused in, one row per wave was slower while EVERY WAVE
+    // reduced mean(x^2) itself (22.1 -> 29.8 us). Since round 4 the block reduces it once (a quarter per wave), and a stand-alone
+    // sweep (tools/probes/gemv_dma_probe.hip, round 5) has one row x 8 chunks ahead of two rows x 4 on every plain shape, lm_head
+    // included (38.3 against 41.2 us). The hooks below select per class: MERV_GEMV_CFG (all launches, "<rows><chunks>"), or
+    // MERV_GEMV_CFG_NORM / _PAIR / _BIG for the launches with a fused norm / the gate-up pair / more than 16384 rows.
+    static const char* cfg = getenv("MERV_GEMV_CFG");
+    static const char* cfg_norm = getenv("MERV_GEMV_CFG_NORM");
+    static const char* cfg_pair = getenv("MERV_GEMV_CFG_PAIR");
+    static const char* cfg_big = getenv("MERV_GEMV_CFG_BIG");
     const long rows_total = (long)a.N + a.Nb + a.Nc;
-    int rows = (!a.W2 && !a.norm_w && rows_total <= 16384) ? 1 : 2, un = rows == 1 ? 8 : 4;
-    // only the three instantiated configurations; one row per wave never with a fused norm (every wave would repeat the reduction)
-    if (cfg && cfg[0] && cfg[1] && !cfg[2]) {
-        const int r = cfg[0] - '0', u = cfg[1] - '0';
-        if ((r == 2 && u == 4) || (r == 1 && (u == 4 || u == 8) && !a.norm_w)) { rows = r; un = u; }
+    // Defaults (round 5, with the block-level norm; q / k / v 20.3 -> 18.5 us, gate / up 32.3 -> 30.7, step 2.99 -> 2.86 ms): one row x 4 chunks
+    // for the launches with a fused norm and for the gate-up pair (1 x 8 there: 20.6 / 42.5 us -- 200 registers), 1 x 8 for the plain
+    // projections of <= 16384 rows, 2 x 4 otherwise.
+    int rows = (a.W2 || a.norm_w || rows_total <= 16384) ? 1 : 2, un = (rows == 1 && !a.W2 && !a.norm_w) ? 8 : 4;
+    const char* c = a.W2 ? (cfg_pair ? cfg_pair : cfg) : a.norm_w ? (cfg_norm ? cfg_norm : cfg) : rows_total > 16384 ? (cfg_big ? cfg_big : cfg) : cfg;
+    const bool hooked = c && c[0] && c[1] && !c[2];
+    if (hooked) {
+        const int r = c[0] - '0', u = c[1] - '0';
+        if ((r == 2 && u == 4) || (r == 1 && (u == 4 || u == 8))) { rows = r; un = u; }
     }
-    if (rows == 1 && un == 8 && !(cfg && cfg[0])) {
+    if (rows == 1 && un == 8 && !hooked && !a.W2 && !a.norm_w) {
         // a trip is 64 lanes x UN chunks and the last one is padded with clamped (wasted) loads: K = 11008 is 1376 chunks = 3 trips
         // of 512 with 160 wasted, or 2 trips of 704 (UN = 11) with 32 -- same per-lane chunk order, so the same bits
         const int nchunk = a.K >> 3;
@@ -881,7 +928,7 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
     }
-    if (rows == 1 && un == 8) return launch_gemv_cfg<1, 8>(a, s);
+    if (rows == 1 && un == 8) return launch_gemv_cfg<1, 8, 8>(a, s);  // (the pair: 2 matrices x 8 chunks = 16 loads per lane)
     if (rows == 1) return launch_gemv_cfg<1, 4>(a, s);
     return launch_gemv_cfg<2, 4>(a, s);
 }
