@@ -44,6 +44,7 @@ TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance (DESIGN.md se
 PMC_TRAFFIC_FILE = "profiles/r05_pmc_gemm_traffic.json"  # falls back to the previous round's file when this one is absent
 PMC_TRAFFIC_FALLBACK = "profiles/r04_pmc_gemm_traffic.json"
 GEMM_CLOCK_FILE = "profiles/r05_gemm_energy_bound.json"  # in-kernel clock per GEMM class (tools/probes/gemm_energy_bound.hip, product mapping)
+POWER_CAP_FILE = "profiles/r05_mfma_issue_order.json"  # bare MFMA loop on random operands (tools/probes/mfma_hold.hip): what the power cap lets the matrix pipe do
 NOMINAL_CLOCK_GHZ = 2.4  # the engine clock the 2.5 PFLOP/s dense bf16 peak is quoted at (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, chip-level parameters; 6.29 TB/s is the measured copy rate)
 # kernel-level profiler classes of libmerv_hip.so (include/merv_hip.h, merv_prof_*): (class, name, bound, kernels)
@@ -115,6 +116,20 @@ def gemm_class_clocks():
                               "same shapes on random data (committed file, not this run)"} for k, v in acc.items() if v[1] > 0}
     except Exception:
         return {}
+
+
+def power_cap_reference():
+    """TFLOP/s and clock of a bare v_mfma_f32_16x16x32_bf16 loop on random operands at the product's issue order (committed probe run, NOT
+    this run): no memory traffic, nothing but MFMAs on every CU -- the rate the 1400 W cap allows the matrix pipe on such data."""
+    f = ROOT / POWER_CAP_FILE
+    try:
+        doc = json.loads(f.read_text())
+        best = max(doc["random_operands"]["orders"], key=lambda o: o["tflops_median"])
+        zero = max(doc["zero_operands"]["orders"], key=lambda o: o["tflops_median"])
+        return {"tflops": best["tflops_median"], "clock_ghz": best["clock_ghz_median"], "tflops_on_zero_operands": zero["tflops_median"],
+                "source": f"{POWER_CAP_FILE}: bare MFMA loop, the GEMM's wave tile in registers, 8 waves per CU, random normal bf16 operands (committed file, not this run)"}
+    except Exception:
+        return None
 
 
 def build_path(device, concurrent=True):
@@ -550,6 +565,10 @@ def main():
             by_kernel.append(ent)
         lib.merv_prof_reset()
         if roof is not None:
+            cap = power_cap_reference()
+            if cap and not args.mxfp8:
+                # `peak` / `frac` stay the contract's nominal 2.5 PFLOP/s; beside them the rate a loop of nothing but MFMAs reaches on random data
+                roof["power_cap_reference"] = dict(cap, frac_of_it=round(roof["achieved"] / cap["tflops"], 4))
             roof["by_kernel"] = by_kernel
             roof["by_kernel_note"] = (f"one HIP-event bracket per kernel launch, encoders on ONE stream, {args.steps} steps; the classes partition the "
                                       f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r05_kernel_roofline.json "

@@ -29,9 +29,10 @@ for rep in (1, 2, 3):
         except Exception as e:
             runs.append({"library": tag, "rep": rep, "error": str(e)})
 doc = {"what": "same-box pair: `bench.py --steps 20 --warmup 5 --no-cpu-baseline` with MERV_HIP_LIB pointing at the previous round's library and at this round's, "
-               "alternating, one GPU session (boxes of the pool differ by +-3 %, so only this pair says whether a round moved the headline). Round 5 changed no kernel "
-               "of the visual path (gemm.hip / attention.hip / rowops.hip device code identical to round 4's apart from register renames); what differs is which encoders share a "
-               "stream and the order they are enqueued in (MervVisualPath.stream_map / enqueue_order), so ms_per_step moves and the one-stream roofline leg does not.",
+               "alternating, one GPU session (boxes of the pool differ by +-3 %, so only this pair says whether a round moved the headline). Round 5 against round 4: "
+               "which encoders share a stream and the order they are enqueued in (MervVisualPath.stream_map / enqueue_order); the eight-phase GEMM's MFMA issue order "
+               "(2 x 2 operand blocks) and its LDS-DMA pieces in scalar-base form; the streamed attention's full key tiles as a compile-time body; the decode GEMV's "
+               "fused RMSNorm as a block-level LDS image with one row x four chunks per wave (e2e leg). Same bits in every kernel.",
        "runs": runs}
 json.dump(doc, open(f"{out}/ab_prev_round.json", "w"), indent=1)
 print(json.dumps([(r.get("library", "")[:7], r.get("ms_per_step"), r.get("gemm_roofline_frac"), r.get("e2e_gen_tok_s")) for r in runs]))
