@@ -189,7 +189,11 @@ template <int EPI>
 constexpr bool epi_needs_row_stats = (EPI == EPI_GENERIC || EPI == EPI_FOLD);
 
 // ---- epilogue through LDS (shared by all tile configurations) ----
-template <int WTM_FULL, int WTN, bool REMAP, int ACT, int EPI, int MSPLIT = 1>
+// ALLVALID (round 5, eight-phase launches whose M is a multiple of the tile): no row of the tile lies past M, so the output stores are
+// unconditional -- hipcc's waitcnt pass counts an instruction behind a per-lane `if (valid)` as "maybe not issued" and waits for one more
+// OLDER operation per such store, which made the later rows of a part wait for the part's own earlier stores -- and both parts' residual rows
+// are requested up front (PIPE with two parts): part 1's rows then sit AHEAD of part 0's stores in the wave's in-order memory queue.
+template <int WTM_FULL, int WTN, bool REMAP, int ACT, int EPI, int MSPLIT = 1, int WHOLE = 0>
 MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FULL / 16], char* smem, int wave, int lane, int m0,
                                int n0, int wr, int wc) {
     // MSPLIT > 1: the wave's rows are finished in MSPLIT passes of WTM rows each (bounds the registers the residual
@@ -237,7 +241,12 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
     // MSPLIT >= 4 (A/B builds, -DMERV_GEMM_EPI_PARTS=4): residual rows are requested ONE PART AHEAD -- part p + 1's loads are issued
     // before part p is staged and stored, into the other half of a two-part register buffer (the registers of one part of twice the rows)
-    constexpr bool PIPE = MSPLIT >= 4;
+    // WHOLE: 0 = any tile; 1 = every row of the tile is valid; 2 / 3 = that AND the launch is known to carry no / a residual (compile time:
+    // behind a run-time `if (p.res)` the loads are "maybe not issued" to the waitcnt pass as well)
+    constexpr bool ALLVALID = WHOLE != 0;
+    constexpr bool PIPE = MSPLIT >= 4 || (WHOLE == 3 && MSPLIT >= 2);
+    const bool has_res = WHOLE == 3 ? true : WHOLE == 2 ? false : p.res != nullptr;
+    const bool mx_out = WHOLE >= 2 ? false : p.mx_out_q != nullptr;  // (the launcher gives MXFP8-output launches the WHOLE = 0 form)
     u32x4 res_ahead[PIPE ? 2 : 1][EP_IT];
     auto res_rows = [&](int part, u32x4(&dst)[EP_IT]) {
 #pragma unroll
@@ -247,11 +256,11 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
             if constexpr (REMAP) {
                 if (p.res_row_mod > 0) rr = rr % p.res_row_mod;
             }
-            dst[it] = p.res ? *(const u32x4*)(p.res + (size_t)((uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + wn0 + ec * 8)) : u32x4{0u, 0u, 0u, 0u};
+            dst[it] = has_res ? *(const u32x4*)(p.res + (size_t)((uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + wn0 + ec * 8)) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     if constexpr (PIPE) {
-        if (p.res) res_rows(0, res_ahead[0]);
+        if (has_res) res_rows(0, res_ahead[0]);
     }
 #pragma unroll
     for (int part = 0; part < MSPLIT; ++part) {
@@ -264,7 +273,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         for (int it = 0; it < EP_IT; ++it) {
             const int r = (elane >> 3) + 8 * it;
             const int m = m0 + wr * WTM_FULL + part * WTM + r;
-            valid[it] = m < p.M;
+            valid[it] = ALLVALID || m < p.M;
             const int mc = valid[it] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
             int orow = mc, rr = mc;
             if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
@@ -277,12 +286,12 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         // one wave-uniform branch around ALL residual loads (a per-element select would serialise them behind
         // vmcnt(0) waits: cdna_hip_programming.md, "Three .s-level traps" (c))
         if constexpr (PIPE) {
-            if (p.res) {  // (uniform) this part's rows were requested a part ago; request the next part's
+            if (has_res) {  // (uniform) this part's rows were requested a part ago; request the next part's
                 if (part + 1 < MSPLIT) res_rows(part + 1, res_ahead[(part + 1) & 1]);
 #pragma unroll
                 for (int it = 0; it < EP_IT; ++it) resv[it] = res_ahead[part & 1][it];
             }
-        } else if (p.res) {
+        } else if (has_res) {
 #pragma unroll
             for (int it = 0; it < EP_IT; ++it) resv[it] = *(const u32x4*)(p.res + (size_t)r_off[it]);
         } else {
@@ -330,7 +339,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         for (int it = 0; it < EP_IT; ++it) {
             const int r = (elane >> 3) + 8 * it;
             u32x4 t = *(const u32x4*)(stg + r * 128 + ((ec ^ (r & 7)) * 16));
-            if (p.res) {
+            if (has_res) {
                 // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -354,7 +363,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 m2 = sum8_dpp(m2);
                 if (ec == it) row_part = float2{sm, m2};  // lane 8 g + it keeps row g + 8 it of this part
             }
-            if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (4 lanes = one 32-column block of the row)
+            if (mx_out) {  // uniform: the result goes out as MXFP8 (4 lanes = one 32-column block of the row)
                 float r[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { r[2 * q] = bflo(t[q]); r[2 * q + 1] = bfhi(t[q]); }
@@ -810,7 +819,7 @@ constexpr int quad_order(int ord, int x) {
     return kk << 3 | ii << 2 | jj;
 }
 
-template <bool REMAP, int ACT, bool MX, int EPI>
+template <bool REMAP, int ACT, bool MX, int EPI, int WHOLE = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // MX = true: the same schedule on MXFP8 operands (OCP e4m3 elements, one E8M0 scale per 32 elements of K,
     // v_mfma_scale_f32_16x16x128_f8f6f4: twice the bf16 MFMA rate and half the operand bytes). A K-tile is still 128
@@ -1146,7 +1155,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     } else if constexpr (DIRECT) {
         gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
     } else {
-        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, MERV_GEMM_EPI_PARTS>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, MERV_GEMM_EPI_PARTS, WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
     MERV_GSTAMP(10);  // part 1's stores are issued
     MERV_PROBE_DRAIN_STORES();
@@ -1170,10 +1179,17 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
     return e;
 }
 
-template <bool REMAP, int ACT, int EPI, bool MX = false>
+#ifndef MERV_GEMM_ALLVALID
+#define MERV_GEMM_ALLVALID 1
+#endif
+template <bool REMAP, int ACT, int EPI, bool MX = false, int WHOLE = 0>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
+    // whole tiles through the LDS epilogue (see gemm_epilogue, WHOLE): bias-only / LayerScale launches with the residual known at compile time
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT == ACT_NONE && (EPI == EPI_PLAIN || EPI == EPI_LS)) {
+        if (a.M % 256 == 0 && !a.mx_out_q) return a.res ? launch_8phase2<REMAP, ACT, EPI, MX, 3>(a, s) : launch_8phase2<REMAP, ACT, EPI, MX, 2>(a, s);
+    }
     constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
-    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI>;
+    auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI, WHOLE>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + 255) / 256, tilesN = a.N / 256;
