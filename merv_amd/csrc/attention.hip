@@ -22,6 +22,9 @@
 
 // Diagnostic builds only (tools/probes/attn_stamps.hip defines MERV_ATTN_STAMPS before including this file): s_memtime
 // stamps per wave into a buffer of their own. The product build compiles none of it.
+#ifndef MERV_ATTN_ABL
+#define MERV_ATTN_ABL 0  // probe builds: 1 = no key-tile loop (memory side alone), 2 = no K / V DMA (compute side alone), 3 = no output stores; results garbage
+#endif
 #ifdef MERV_ATTN_STAMPS
 __device__ unsigned long long* g_attn_stamps = nullptr;  // [block][wave][32]
 #define MERV_STAMP(k)                                                                                       \
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         // the first P.V product. The waits that order these DMAs against the LDS reads are the two explicit ones below.
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
         auto glds16 = [&](const bf16_t* gsrc, unsigned lds_dst) {
+            if constexpr (MERV_ATTN_ABL == 2) return;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -514,7 +518,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         }
         MERV_STAMP(5 + 4 * t);
     };
-    if constexpr (RES) {  // L in (256, 264]: four full tiles, then the 1 .. 8 keys of the fifth
+    if constexpr (MERV_ATTN_ABL == 1) {
+    } else if constexpr (RES) {  // L in (256, 264]: four full tiles, then the 1 .. 8 keys of the fifth
         for (int t = 0; t < ntiles - 1; ++t) tile_body(t, std::integral_constant<int, 1>{});
         tile_body(ntiles - 1, std::integral_constant<int, 2>{});
     } else {
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     *(u32x2*)(p.mx_q + (size_t)row * D + col) = q8;
                     if ((c & 3) == 0) p.mx_scales[mx_scale_offset(row, col >> 5, p.mx_groups)] = (uint8_t)sb;
                 }
-            } else if (q0 + rr < L) {
+            } else if (q0 + rr < L && (MERV_ATTN_ABL != 3 || p.L < 0)) {
                 *(u32x4*)(p.out + ((size_t)seq * L + q0 + rr) * D + head * HD + c * 8) = v;
             }
         }

@@ -37,6 +37,9 @@ doc = {"what": "same-box pair: `bench.py --steps 20 --warmup 5 --no-cpu-baseline
 json.dump(doc, open(f"{out}/ab_prev_round.json", "w"), indent=1)
 print(json.dumps([(r.get("library", "")[:7], r.get("ms_per_step"), r.get("gemm_roofline_frac"), r.get("e2e_gen_tok_s")) for r in runs]))
 PY
+# the N > 1 code path on one rank (RCCL process group of 1 rank): plain and under torch.distributed.run as the driver launches it
+MERV_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python3 bench.py --steps 10 --warmup 3 --no-e2e > $OUT/forcedist_world1.json 2> $OUT/forcedist_world1.err; echo "forcedist rc $?"; grep "\[bench\]" $OUT/forcedist_world1.err | head -3
+MERV_BENCH_FORCE_DISTRIBUTED=1 timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --no-e2e --no-cpu-baseline > $OUT/forcedist_torchrun.json 2> $OUT/forcedist_torchrun.err; echo "torchrun rc $?"; tail -c 300 $OUT/forcedist_torchrun.json
 for B in 1 2 4 8 16; do
   timeout 300 python3 bench.py --batch $B --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-prof > $OUT/sweep_b$B.json 2> $OUT/sweep_b$B.err
 done
