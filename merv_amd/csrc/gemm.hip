@@ -241,12 +241,16 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     char* stg = smem + wave * (WTM * 128);  // [WTM rows][128 B], 16-byte chunks XOR-swizzled by (row & 7)
     // MSPLIT >= 4 (A/B builds, -DMERV_GEMM_EPI_PARTS=4): residual rows are requested ONE PART AHEAD -- part p + 1's loads are issued
     // before part p is staged and stored, into the other half of a two-part register buffer (the registers of one part of twice the rows)
-    // WHOLE: 0 = any tile; 1 = every row of the tile is valid; 2 / 3 = that AND the launch is known to carry no / a residual (compile time:
-    // behind a run-time `if (p.res)` the loads are "maybe not issued" to the waitcnt pass as well)
+    // WHOLE: 0 = any tile, every optional term decided at run time. Otherwise a bit set, all of it compile time: bit 0 = every row of the tile is
+    // valid and the output is bf16 (no MXFP8), bit 1 = a residual, bit 2 = LayerNorm partials out, bit 3 = the row-indexed add. Behind a run-time
+    // test a memory instruction is "maybe not issued" to hipcc's waitcnt pass, and the tests in every row's body kept it from batching the part's
+    // read-backs: the static forms are straight-line code (stage, read back two ahead, store).
     constexpr bool ALLVALID = WHOLE != 0;
-    constexpr bool PIPE = MSPLIT >= 4 || (WHOLE == 3 && MSPLIT >= 2);
-    const bool has_res = WHOLE == 3 ? true : WHOLE == 2 ? false : p.res != nullptr;
-    const bool mx_out = WHOLE >= 2 ? false : p.mx_out_q != nullptr;  // (the launcher gives MXFP8-output launches the WHOLE = 0 form)
+    constexpr bool PIPE = MSPLIT >= 4 || ((WHOLE & 2) && MSPLIT >= 2);
+    const bool has_res = WHOLE ? (WHOLE & 2) != 0 : p.res != nullptr;
+    const bool mx_out = WHOLE ? false : p.mx_out_q != nullptr;  // (the launcher gives MXFP8-output launches the WHOLE = 0 form)
+    const bool has_stats = WHOLE ? (WHOLE & 4) != 0 : p.stats_out != nullptr;
+    const bool has_row_add = WHOLE ? (WHOLE & 8) != 0 : p.row_add != nullptr;
     u32x4 res_ahead[PIPE ? 2 : 1][EP_IT];
     auto res_rows = [&](int part, u32x4(&dst)[EP_IT]) {
 #pragma unroll
@@ -302,7 +306,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
         // most two groups; both candidate rows of the table are loaded once (this lane's 8 columns) and selected per output row
         float ra[2][8];
         int ra_boundary = 0x7fffffff;
-        if (p.row_add) {  // uniform
+        if (has_row_add) {  // uniform
             const int mb = __builtin_amdgcn_readfirstlane(m0 + wr * WTM_FULL + part * WTM) + p.row_add_row0;
             const int f0 = mb / p.row_add_div, i0 = f0 % p.row_add_mod, i1 = i0 + 1 == p.row_add_mod ? 0 : i0 + 1;
             ra_boundary = (f0 + 1) * p.row_add_div - p.row_add_row0;  // in this launch's row numbering
@@ -345,13 +349,13 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 for (int q = 0; q < 4; ++q)
                     t[q] = pack2bf(bflo(t[q]) + bflo(resv[it][q]), bfhi(t[q]) + bfhi(resv[it][q]));
             }
-            if (p.row_add) {  // uniform: bf16(x + table row), x already rounded by the residual add
+            if (has_row_add) {  // uniform: bf16(x + table row), x already rounded by the residual add
                 const bool second = m0 + wr * WTM_FULL + part * WTM + r >= ra_boundary;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     t[q] = pack2bf(bflo(t[q]) + (second ? ra[1][2 * q] : ra[0][2 * q]), bfhi(t[q]) + (second ? ra[1][2 * q + 1] : ra[0][2 * q + 1]));
             }
-            if (p.stats_out) {  // uniform: {sum, M2} of this row's 64 columns (the 8 lanes ec = 0..7 hold 8 values each)
+            if (has_stats) {  // uniform: {sum, M2} of this row's 64 columns (the 8 lanes ec = 0..7 hold 8 values each)
                 float f[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { f[2 * q] = bflo(t[q]); f[2 * q + 1] = bfhi(t[q]); }
@@ -381,7 +385,7 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 MERV_PROBE_STORE16(t, (u32x4*)(p.C + (size_t)c_off[it]));
             }
         }
-        if (p.stats_out) {
+        if (has_stats) {
             // lane l holds row (l >> 3) + 8 (l & 7): transpose the 8 x 8 lane grid so that lane L holds row L, and the part's
             // partials go out as ONE store of 8 * EP_IT consecutive float2 (layout [N / 64][M][2]: rows contiguous per column tile)
             const int src = 8 * (elane & 7) + (elane >> 3);
@@ -418,10 +422,14 @@ MERV_DEVICE float max_rows4(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
-template <int WTM_FULL, bool REMAP, int ACT, int EPI, int MSPLIT = 1>
+template <int WTM_FULL, bool REMAP, int ACT, int EPI, int MSPLIT = 1, int WHOLE = 0>
 MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FULL / 16], int lane, int m0, int n0, int wr, int wc) {
     constexpr int WTM = WTM_FULL / MSPLIT;
     constexpr int MI = WTM / 16;
+    // WHOLE: as gemm_epilogue (0 = run-time tests; else static: bit 0 whole tile and bf16 output, bit 1 residual, bit 2 LayerNorm partials out)
+    const bool has_res = WHOLE ? (WHOLE & 2) != 0 : p.res != nullptr;
+    const bool has_stats = WHOLE ? (WHOLE & 4) != 0 : p.stats_out != nullptr;
+    const bool mx_out = WHOLE ? false : p.mx_out_q != nullptr;
     // opaque copy of the lane id: keeps the epilogue's index arithmetic below the K-loop (see gemm_epilogue)
     int elane = lane;
     asm volatile("" : "+v"(elane));
@@ -457,7 +465,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
             const int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
-            valid[j] = m < p.M;
+            valid[j] = WHOLE != 0 || m < p.M;
             const int mc = valid[j] ? m : p.M - 1;  // clamp instead of branching: loads stay unconditional
             int orow = mc, rr = mc;
             if constexpr (REMAP) {  // patch-embedding launch only: scatter past prefix tokens, position row m % P
@@ -468,7 +476,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
             r_off[j] = (uint32_t)MERV_PROBE_OUT_ROW(rr) * (uint32_t)p.ldres + nl;
         }
         // one wave-uniform branch around ALL residual loads
-        if (p.res) {
+        if (has_res) {
 #pragma unroll
             for (int j = 0; j < MI; ++j)
 #pragma unroll
@@ -496,7 +504,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                     t[nh][2 * e] = pack2bf(lo[0], lo[1]);
                     t[nh][2 * e + 1] = pack2bf(hi[0], hi[1]);
                 }
-                if (p.res) {
+                if (has_res) {
                     // bf16(linear) + bf16(residual), rounded once more: the reference's own order under autocast
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
@@ -504,7 +512,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                 }
             }
             const int m = m0 + wr * WTM_FULL + part * WTM + j * 16 + frow;
-            if (p.stats_out) {  // uniform: {sum, M2} of this row's 64 columns: 16 values here, the other 48 in lanes l ^ 16, ^ 32, ^ 48
+            if (has_stats) {  // uniform: {sum, M2} of this row's 64 columns: 16 values here, the other 48 in lanes l ^ 16, ^ 32, ^ 48
                 float f[16];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { f[2 * q] = bflo(t[q >> 2][q & 3]); f[2 * q + 1] = bfhi(t[q >> 2][q & 3]); }
@@ -522,7 +530,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                 const float m2 = sum_rows4(m2a + m2b);
                 if (fq == j) row_part = float2{sm, m2};  // lane 16 j + frow keeps row 16 j + frow of this part
             }
-            if (p.mx_out_q) {  // uniform: the result goes out as MXFP8 (the four lanes of a row = one 32-column block per nh)
+            if (mx_out) {  // uniform: the result goes out as MXFP8 (the four lanes of a row = one 32-column block per nh)
 #pragma unroll
                 for (int nh = 0; nh < 2; ++nh) {
                     float r[8];
@@ -547,7 +555,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                 MERV_PROBE_STORE16(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
             }
         }
-        if (p.stats_out) {  // one store of 16 MI consecutive float2 per part (layout [N / 64][M][2])
+        if (has_stats) {  // one store of 16 MI consecutive float2 per part (layout [N / 64][M][2])
             const int m = m0 + wr * WTM_FULL + part * WTM + elane;
             if (elane < 16 * MI && m < p.M)
                 *(float2*)(p.stats_out + 2 * ((size_t)(wn0 >> 6) * p.stats_ld + m)) = row_part;
@@ -1153,7 +1161,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else if constexpr (DIRECT) {
-        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2>(p, acc, lane, m0, n0, wr, wc);
+        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2, WHOLE>(p, acc, lane, m0, n0, wr, wc);
     } else {
         gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, MERV_GEMM_EPI_PARTS, WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
@@ -1185,8 +1193,23 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
 template <bool REMAP, int ACT, int EPI, bool MX = false, int WHOLE = 0>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
     // whole tiles through the LDS epilogue (see gemm_epilogue, WHOLE): bias-only / LayerScale launches with the residual known at compile time
-    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT == ACT_NONE && (EPI == EPI_PLAIN || EPI == EPI_LS)) {
-        if (a.M % 256 == 0 && !a.mx_out_q) return a.res ? launch_8phase2<REMAP, ACT, EPI, MX, 3>(a, s) : launch_8phase2<REMAP, ACT, EPI, MX, 2>(a, s);
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT != ACT_NONE && gemm_direct_epilogue<ACT> && (EPI == EPI_PLAIN || EPI == EPI_FOLD)) {
+        // activation launches (fc1) through the register epilogue: the static form when nothing optional is asked for
+        if (a.M % 256 == 0 && !a.mx_out_q && !a.res && !a.stats_out && !a.row_add) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);
+    }
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT == ACT_NONE && (EPI == EPI_PLAIN || EPI == EPI_LS || EPI == EPI_FOLD)) {
+        // whole tiles through the LDS epilogue: the static forms the encoder stacks produce (see gemm_epilogue, WHOLE)
+        if (a.M % 256 == 0 && !a.mx_out_q) {
+            const int f = 1 | (a.res ? 2 : 0) | (a.stats_out ? 4 : 0) | (a.row_add ? 8 : 0);
+            if (f == 1) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);       // qkv, temporal qkv, the projector
+            if constexpr (EPI != EPI_FOLD) {
+                if (f == 3) return launch_8phase2<REMAP, ACT, EPI, MX, 3>(a, s);   // + residual
+                if (f == 7) return launch_8phase2<REMAP, ACT, EPI, MX, 7>(a, s);   // + residual + LayerNorm partials (proj, fc2)
+                if constexpr (EPI == EPI_PLAIN) {
+                    if (f == 15) return launch_8phase2<REMAP, ACT, EPI, MX, 15>(a, s);  // + the next block's temporal embedding (LanguageBind fc2)
+                }
+            }
+        }
     }
     constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
     auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI, WHOLE>;
