@@ -132,7 +132,9 @@ MERV_DEVICE void write_vt_pair(char* vt_lds, int vt_row_bytes, int kp, int c, u3
 // blocks per CU.
 constexpr int XQ_ROWS = 8, XQ_SLOTS = 5;
 constexpr int RES_KROWS = 264, RES_VROWS = 272;  // K rows past 264 are read (and masked) from whatever follows; V rows must be finite
-template <bool VTR, int NW, int QPW, bool XQ = false, bool RES = false>
+// MXQ (compile time since round 5): the output goes out as MXFP8; with the choice a run-time test inside every row chunk of the output loop hipcc issued
+// the chunks' LDS read-backs one by one, each waited for in front of its own store (as in the GEMM epilogue, gemm.hip WHOLE)
+template <bool VTR, int NW, int QPW, bool XQ = false, bool RES = false, bool MXQ = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     static_assert(!RES || (VTR && XQ && NW * QPW * 32 == 256), "resident form: 4 x 2 block with the extra-row split only");
     constexpr int NT = NW * 64;
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         for (int it = 0; it < 4; ++it) {
             const int rr = (lane >> 3) + 8 * it, c = lane & 7;
             const u32x4 v = *(const u32x4*)(stg + rr * 128 + ((c ^ (rr & 7)) * 16));
-            if (p.mx_q) {  // uniform: lanes c = 4b .. 4b+3 hold the 32-column block b of this head's row
+            if constexpr (MXQ) {  // lanes c = 4b .. 4b+3 hold the 32-column block b of this head's row
                 float f[8];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) { f[2 * w] = bflo(v[w]); f[2 * w + 1] = bfhi(v[w]); }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     *(u32x2*)(p.mx_q + (size_t)row * D + col) = q8;
                     if ((c & 3) == 0) p.mx_scales[mx_scale_offset(row, col >> 5, p.mx_groups)] = (uint8_t)sb;
                 }
-            } else if (q0 + rr < L && (MERV_ATTN_ABL != 3 || p.L < 0)) {
+            } else if ((XQ || q0 + rr < L) && (MERV_ATTN_ABL != 3 || p.L < 0)) {  // (XQ: the block's eight tiles are whole, the rows past them go the other way)
                 *(u32x4*)(p.out + ((size_t)seq * L + q0 + rr) * D + head * HD + c * 8) = v;
             }
         }
@@ -1001,7 +1003,10 @@ static hipError_t launch_attn_cfg(const AttnArgs& a, hipStream_t s) {
     const int rows = NW * QPW * 32;
     dim3 grid(XQ ? 1 : (a.L + rows - 1) / rows, a.heads, a.nseq);
     ProfScope pk(RES ? PROF_K_ATTN_RES : PROF_K_ATTN_STREAM, s, 4.0 * a.nseq * (double)a.L * a.L * a.D, 2.0 * 4.0 * a.nseq * (double)a.L * a.D);
-    if (RES || use_vtr())
+    if (a.mx_q) {  // MXFP8 output (opt-in mode): its own instantiations
+        if (RES || use_vtr()) hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ, RES, true>), grid, dim3(NW * 64), 0, s, a);
+        else if constexpr (!RES) hipLaunchKernelGGL((attn_kernel<false, NW, QPW, XQ, false, true>), grid, dim3(NW * 64), 0, s, a);
+    } else if (RES || use_vtr())
         hipLaunchKernelGGL((attn_kernel<true, NW, QPW, XQ, RES>), grid, dim3(NW * 64), 0, s, a);
     else if constexpr (!RES)
         hipLaunchKernelGGL((attn_kernel<false, NW, QPW, XQ, false>), grid, dim3(NW * 64), 0, s, a);
