@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
         using NE_t = std::integral_constant<int, TAILK == 2 ? 4 : 16>;
 #pragma unroll
         for (int qi = 0; qi < QPW; ++qi) {
-            if (q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding
+            if (!XQ && q_base + qi * 32 >= L) continue;  // wave-uniform: this query tile is entirely padding (XQ: the block's tiles are whole)
             f32x16(&sa)[2] = sacc[S_FIRST ? qi : 0];
             if constexpr (!S_FIRST) scores(qf[qi], sa, t == 0 ? 0.f : -m_run[qi]);
             // ---- online softmax (this lane: one query, 32 of the tile's 64 keys) ----
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int key_base = kb * 32 + 16 * s2;
-                    if constexpr (RES) { if (kv0 + key_base >= L) continue; }  // all 16 keys are padding (P = 0) and their V rows are not resident
+                    if constexpr (RES && TAILK != 1) { if (kv0 + key_base >= L) continue; }  // all 16 keys are padding (P = 0) and their V rows are not resident (a full tile has none: no test, one basic block)
                     const bf16x8 pf = pack8(sa[kb], 8 * s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                     if (kb == 1 && !both_halves) continue;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        if constexpr (RES) { if (kv0 + kb * 32 + 16 * s2 >= L) continue; }
+                        if constexpr (RES && TAILK != 1) { if (kv0 + kb * 32 + 16 * s2 >= L) continue; }
                         const bf16x8 pf = pack8(sx[kb], 8 * s2);
 #pragma unroll
                         for (int db = 0; db < 2; ++db) {
