@@ -161,7 +161,9 @@ struct GemvLds {
 // two bf16 roundings per element: ~80 VALU instructions per chunk against 16-32 of multiply-add for the wave's rows, and two more global
 // loads per chunk): the q / k / v launch ran 20.3 us against 17.0 for the same bytes without a norm. Same values (the formula and its
 // rounding points are unchanged), same accumulation order: same bits.
-template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS>
+// EXACT (round 5): K / 8 is a multiple of the trip (64 lanes x UN chunks) and N of the block's rows -- no chunk is ever clamped or zeroed, no row
+// past N: the per-chunk compares and selects (as many VALU instructions as the multiply-adds of a one-row wave) are compiled out
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS, bool EXACT = false>
 MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x4* xn_lds) {  // xn_lds (NORM): K / 8 chunks of LDS
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: row pointers stay in SGPRs
@@ -187,7 +189,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
     const bf16_t* wrow[NW_MATS][GEMV_ROWS];
 #pragma unroll
     for (int r = 0; r < GEMV_ROWS; ++r) {
-        const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+        const int n = EXACT || n0 + r < p.N ? n0 + r : p.N - 1;
         wrow[0][r] = p.W + (size_t)n * p.K;
         if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
     }
@@ -197,10 +199,10 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
     // K = 11008 launch).
     u32x4 wv[NW_MATS][GEMV_ROWS][UN], xv[UN];
     auto issue_w = [&](int c) {
-        c = c < nchunk ? c : 0;  // (rows shorter than 64 chunks: the lanes past the end load a valid chunk and multiply nothing)
+        if constexpr (!EXACT) c = c < nchunk ? c : 0;  // (rows shorter than 64 chunks: the lanes past the end load a valid chunk and multiply nothing)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
-            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+            const int cu = EXACT || c + 64 * u < nchunk ? c + 64 * u : c;
 #pragma unroll
             for (int m = 0; m < NW_MATS; ++m)
 #pragma unroll
@@ -209,10 +211,10 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
     };
     auto issue_x = [&](int c) {  // (NORM: the chunks come from the LDS image at their use)
         if constexpr (!NORM) {
-            c = c < nchunk ? c : 0;
+            if constexpr (!EXACT) c = c < nchunk ? c : 0;
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+                const int cu = EXACT || c + 64 * u < nchunk ? c + 64 * u : c;
                 xv[u] = *(const u32x4*)(p.x + cu * 8);
             }
         }
@@ -271,12 +273,12 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
         for (int u = 0; u < UN; ++u) {
             float xf[8];
             if constexpr (NORM) {
-                const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+                const int cu = EXACT || c + 64 * u < nchunk ? c + 64 * u : c;
                 unpack8f(xn_lds[cu], xf);
             } else {
                 unpack8f(xv[u], xf);
             }
-            if (c + 64 * u >= nchunk) {
+            if (!EXACT && c + 64 * u >= nchunk) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xf[j] = 0.f;
             }
@@ -315,13 +317,13 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
     }
 }
 
-template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2>
+template <int NW_MATS, int UN, bool NORM, int GEMV_ROWS = 2, bool EXACT = false>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p) {
     // NORM: the normalised input's image, dynamic LDS sized by the launcher (2 K bytes: 8 KB at K = 4096 -- a fixed 32 KB image halved
     // the resident blocks and cost the q / k / v launch 1.5 us)
     extern __shared__ __attribute__((aligned(16))) char gemv_dyn_lds[];
     __shared__ GemvLds lds;
-    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS>(p, blockIdx.x, lds, (u32x4*)gemv_dyn_lds);
+    gemv_body<NW_MATS, UN, NORM, GEMV_ROWS, EXACT>(p, blockIdx.x, lds, (u32x4*)gemv_dyn_lds);
 }
 
 // ---- rotary embedding of q and k at the current position + cache update ----
@@ -877,13 +879,27 @@ static hipError_t launch_gemv_cfg(const DecodeGemvArgs& a, hipStream_t s) {
     const int rows_per_block = ROWS * GEMV_WAVES;
     dim3 grid((a.N + a.Nb + a.Nc + rows_per_block - 1) / rows_per_block);
     const dim3 blk(GEMV_WAVES * 64);
+    // EXACT: whole trips and whole blocks (every matrix of a q / k / v launch a multiple of the block's rows)
+    const int nchunk = a.K >> 3;
+    const bool rows_whole = a.N % rows_per_block == 0 && a.Nb % rows_per_block == 0 && a.Nc % rows_per_block == 0;
     if (a.W2) {
-        if (a.norm_w) hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, true, ROWS>), grid, blk, 2 * a.K, s, a);
-        else hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, false, ROWS>), grid, blk, 0, s, a);
-    } else if (a.norm_w) {
-        hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS>), grid, blk, 2 * a.K, s, a);
+        const bool exact = rows_whole && nchunk % (64 * UN_PAIR) == 0;
+        if (a.norm_w) {
+            if (exact) hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, true, ROWS, true>), grid, blk, 2 * a.K, s, a);
+            else hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, true, ROWS>), grid, blk, 2 * a.K, s, a);
+        } else {
+            if (exact) hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, false, ROWS, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((gemv_kernel<2, UN_PAIR, false, ROWS>), grid, blk, 0, s, a);
+        }
     } else {
-        hipLaunchKernelGGL((gemv_kernel<1, UN, false, ROWS>), grid, blk, 0, s, a);
+        const bool exact = rows_whole && nchunk % (64 * UN) == 0;
+        if (a.norm_w) {
+            if (exact) hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS, true>), grid, blk, 2 * a.K, s, a);
+            else hipLaunchKernelGGL((gemv_kernel<1, UN, true, ROWS>), grid, blk, 2 * a.K, s, a);
+        } else {
+            if (exact) hipLaunchKernelGGL((gemv_kernel<1, UN, false, ROWS, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((gemv_kernel<1, UN, false, ROWS>), grid, blk, 0, s, a);
+        }
     }
     return hipGetLastError();
 }
