@@ -754,6 +754,7 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* logit
 // configuration): the result is bit-identical to merv_decode_attention_fused + merv_decode_gemv. Workgroup 0 also stores the
 // merged vector (the separate path's attention output).
 constexpr int OM_WAVES = 8, OM_ROWS = 2, OM_UN = 8;
+template <bool EXACT>  // whole trips (K / 8 a multiple of 512 chunks) and whole blocks: no clamps, no zeroed chunks (as gemv_body)
 __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojMergeArgs p) {
     extern __shared__ __attribute__((aligned(16))) char om_smem[];
     bf16_t* x_lds = (bf16_t*)om_smem;  // [K]
@@ -763,13 +764,13 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
     const int K = p.H * 128, nchunk = K >> 3;
     const bf16_t* wrow[OM_ROWS];
 #pragma unroll
-    for (int r = 0; r < OM_ROWS; ++r) wrow[r] = p.W + (size_t)(n0 + r < p.N ? n0 + r : p.N - 1) * K;
+    for (int r = 0; r < OM_ROWS; ++r) wrow[r] = p.W + (size_t)(EXACT || n0 + r < p.N ? n0 + r : p.N - 1) * K;
     u32x4 wv[OM_ROWS][OM_UN];
     auto issue_w = [&](int c) {
-        c = c < nchunk ? c : 0;
+        if constexpr (!EXACT) c = c < nchunk ? c : 0;
 #pragma unroll
         for (int u = 0; u < OM_UN; ++u) {
-            const int cu = c + 64 * u < nchunk ? c + 64 * u : c;
+            const int cu = EXACT || c + 64 * u < nchunk ? c + 64 * u : c;
 #pragma unroll
             for (int r = 0; r < OM_ROWS; ++r) wv[r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[r] + cu * 8));
         }
@@ -829,8 +830,8 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
         for (int u = 0; u < OM_UN; ++u) {
             float xf[8];
             const int cu = c + 64 * u;
-            unpack8f(*(const u32x4*)(x_lds + (cu < nchunk ? cu : 0) * 8), xf);
-            if (cu >= nchunk) {
+            unpack8f(*(const u32x4*)(x_lds + (EXACT || cu < nchunk ? cu : 0) * 8), xf);
+            if (!EXACT && cu >= nchunk) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xf[j] = 0.f;
             }
@@ -1001,7 +1002,9 @@ hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream
 hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s) {
     if (a.H <= 0 || a.nsplit <= 0 || a.N <= 0 || a.H * 256 > 64 * 1024) return hipErrorInvalidValue;  // x image in LDS: 256 B per head
     const int rows_per_block = OM_WAVES * OM_ROWS;
-    hipLaunchKernelGGL(oproj_merge_kernel, dim3((a.N + rows_per_block - 1) / rows_per_block), dim3(OM_WAVES * 64), a.H * 256, s, a);
+    const dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
+    if (a.N % rows_per_block == 0 && (a.H * 16) % (64 * OM_UN) == 0) hipLaunchKernelGGL(oproj_merge_kernel<true>, grid, dim3(OM_WAVES * 64), a.H * 256, s, a);
+    else hipLaunchKernelGGL(oproj_merge_kernel<false>, grid, dim3(OM_WAVES * 64), a.H * 256, s, a);
     return hipGetLastError();
 }
 
