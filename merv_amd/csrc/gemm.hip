@@ -576,6 +576,11 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
 #ifndef MERV_GEMM_EPI_PARTS
 #define MERV_GEMM_EPI_PARTS 2
 #endif
+// the static (whole-tile) forms: 4 x 32 rows, a residual's rows one part ahead -- with exact waits the finer pipeline wins (GEMM time -0.9 %), where
+// the run-time form lost 1 us per tile to vmcnt(0)s (round 5, first half)
+#ifndef MERV_GEMM_EPI_PARTS_WHOLE
+#define MERV_GEMM_EPI_PARTS_WHOLE 4
+#endif
 template <int ACT>
 constexpr bool gemm_direct_epilogue = (MERV_GEMM_EPILOGUE == 1) || (MERV_GEMM_EPILOGUE == 2 && ACT != ACT_NONE);
 
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     } else if constexpr (DIRECT) {
         gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2, WHOLE>(p, acc, lane, m0, n0, wr, wc);
     } else {
-        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, MERV_GEMM_EPI_PARTS, WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, (WHOLE ? MERV_GEMM_EPI_PARTS_WHOLE : MERV_GEMM_EPI_PARTS), WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
     MERV_GSTAMP(10);  // part 1's stores are issued
     MERV_PROBE_DRAIN_STORES();
