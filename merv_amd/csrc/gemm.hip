@@ -581,6 +581,9 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
 #ifndef MERV_GEMM_EPI_PARTS_WHOLE
 #define MERV_GEMM_EPI_PARTS_WHOLE 4
 #endif
+#ifndef MERV_GEMM_EPI_PARTS_DIRECT_WHOLE
+#define MERV_GEMM_EPI_PARTS_DIRECT_WHOLE 2  // (the register epilogue of the activation launches)
+#endif
 template <int ACT>
 constexpr bool gemm_direct_epilogue = (MERV_GEMM_EPILOGUE == 1) || (MERV_GEMM_EPILOGUE == 2 && ACT != ACT_NONE);
 
@@ -1166,7 +1169,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else if constexpr (DIRECT) {
-        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 2, WHOLE>(p, acc, lane, m0, n0, wr, wc);
+        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, (WHOLE ? MERV_GEMM_EPI_PARTS_DIRECT_WHOLE : 2), WHOLE>(p, acc, lane, m0, n0, wr, wc);
     } else {
         gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, (WHOLE ? MERV_GEMM_EPI_PARTS_WHOLE : MERV_GEMM_EPI_PARTS), WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
