@@ -1201,19 +1201,16 @@ inline hipError_t ensure_dynamic_lds(const void* kern, int lds_bytes, bool (&don
 template <bool REMAP, int ACT, int EPI, bool MX = false, int WHOLE = 0>
 hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
     // whole tiles through the LDS epilogue (see gemm_epilogue, WHOLE): bias-only / LayerScale launches with the residual known at compile time
-    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT != ACT_NONE && gemm_direct_epilogue<ACT> && (EPI == EPI_PLAIN || EPI == EPI_FOLD)) {
-        // activation launches (fc1) through the register epilogue: the static form when nothing optional is asked for
-        if (a.M % 256 == 0 && !a.mx_out_q && !a.res && !a.stats_out && !a.row_add) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);
-    }
-    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && ACT == ACT_NONE && (EPI == EPI_PLAIN || EPI == EPI_LS || EPI == EPI_FOLD)) {
-        // whole tiles through the LDS epilogue: the static forms the encoder stacks produce (see gemm_epilogue, WHOLE)
+    // Whole tiles (M a multiple of 256, bf16 output): the static epilogue forms the encoder stacks produce (gemm_epilogue, WHOLE) -- every optional
+    // term a template flag
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && !MX && (EPI == EPI_PLAIN || EPI == EPI_LS || EPI == EPI_FOLD)) {
         if (a.M % 256 == 0 && !a.mx_out_q) {
             const int f = 1 | (a.res ? 2 : 0) | (a.stats_out ? 4 : 0) | (a.row_add ? 8 : 0);
-            if (f == 1) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);       // qkv, temporal qkv, the projector
-            if constexpr (EPI != EPI_FOLD) {
-                if (f == 3) return launch_8phase2<REMAP, ACT, EPI, MX, 3>(a, s);   // + residual
-                if (f == 7) return launch_8phase2<REMAP, ACT, EPI, MX, 7>(a, s);   // + residual + LayerNorm partials (proj, fc2)
-                if constexpr (EPI == EPI_PLAIN) {
+            if (f == 1) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);           // qkv, temporal qkv, the projector, fc1
+            if constexpr (EPI != EPI_FOLD && ACT == ACT_NONE) {
+                if (f == 3) return launch_8phase2<REMAP, ACT, EPI, MX, 3>(a, s);       // + residual
+                if (f == 7) return launch_8phase2<REMAP, ACT, EPI, MX, 7>(a, s);       // + residual + LayerNorm partials (proj, fc2)
+                if constexpr (EPI == EPI_PLAIN && !gemm_direct_epilogue<ACT>) {
                     if (f == 15) return launch_8phase2<REMAP, ACT, EPI, MX, 15>(a, s);  // + the next block's temporal embedding (LanguageBind fc2)
                 }
             }
