@@ -14,10 +14,10 @@ import sys
 
 # kernel-name pattern -> by_kernel class name (bench.py KERNEL_CLASSES)
 RULES = [
-    (r"gemm_bf16_8phase_kernel<false, 0, false(, \d)*>", "gemm eight-phase, no activation"),   # <REMAP, ACT, MX(, EPI: round 4)(, WHOLE: round 5)>
-    (r"gemm_bf16_8phase_kernel<false, [123], false(, \d)*>", "gemm eight-phase + activation epilogue"),
+    (r"gemm_bf16_8phase_kernel<false, 0, false(, \d+)*>", "gemm eight-phase, no activation"),   # <REMAP, ACT, MX(, EPI: round 4)(, WHOLE: round 5)>
+    (r"gemm_bf16_8phase_kernel<false, [123], false(, \d+)*>", "gemm eight-phase + activation epilogue"),
     (r"gemm_bf16_kernel<", "gemm small tiles"),
-    (r"attn_kernel<true, 4, 2, true, true>", "attention, K/V resident"),
+    (r"attn_kernel<true, 4, 2, true, true(, \w+)?>", "attention, K/V resident"),
     (r"(?<!temporal_)attn_kernel<", "attention, K/V streamed"),
     (r"temporal_attn_kernel", "temporal attention"),
     (r"layernorm_kernel", "LayerNorm"),

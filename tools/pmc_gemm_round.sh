@@ -17,12 +17,12 @@ import csv, sys, glob, json, re, collections
 out = sys.argv[1]
 STEPS = 2
 CLASSES = [
-    (r"gemm_bf16_8phase_kernel<false, 0, false, 3(, \d)?>", "eight-phase, folded LayerNorm (qkv)"),
-    (r"gemm_bf16_8phase_kernel<false, 0, false, 1(, \d)?>", "eight-phase, bias only (proj / fc2 / temporal qkv, proj / projector; ViViT, SigLIP, LanguageBind)"),
-    (r"gemm_bf16_8phase_kernel<false, 0, false, 2(, \d)?>", "eight-phase, LayerScale (DINOv2 proj / fc2)"),
-    (r"gemm_bf16_8phase_kernel<false, [123], false, \d(, \d)?>", "eight-phase + activation, direct epilogue (fc1)"),
+    (r"gemm_bf16_8phase_kernel<false, 0, false, 3(, \d+)?>", "eight-phase, folded LayerNorm (qkv)"),
+    (r"gemm_bf16_8phase_kernel<false, 0, false, 1(, \d+)?>", "eight-phase, bias only (proj / fc2 / temporal qkv, proj / projector; ViViT, SigLIP, LanguageBind)"),
+    (r"gemm_bf16_8phase_kernel<false, 0, false, 2(, \d+)?>", "eight-phase, LayerScale (DINOv2 proj / fc2)"),
+    (r"gemm_bf16_8phase_kernel<false, [123], false, \d(, \d+)?>", "eight-phase + activation, direct epilogue (fc1)"),
     (r"gemm_bf16_kernel<", "small tiles"),
-    (r"attn_kernel<true, 4, 2, true, true>", "attention, K/V resident"),
+    (r"attn_kernel<true, 4, 2, true, true(, \w+)?>", "attention, K/V resident"),
     (r"(?<!temporal_)attn_kernel<", "attention, K/V streamed"),
     (r"temporal_attn_kernel", "temporal attention"),
 ]
