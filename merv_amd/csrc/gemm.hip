@@ -598,7 +598,7 @@ MERV_DEVICE void wait_dma_barrier() {
 //   wait(my DMA of tile kt) ; barrier  => tile kt is complete in LDS AND every wave has finished reading tile kt-1
 //   issue DMA of tile kt+NSTAGE-1 into the stage tile kt-1 occupied, one 1-KiB piece after each row of MFMAs
 //   (a DMA piece costs ~60-180 issue cycles: spread out, the SIMD's other wave fills the gap with its MFMAs)
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI, int WHOLE = 0>  // WHOLE: static epilogue form (gemm_epilogue)
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmArgs p) {
     constexpr bool DIRECT = gemm_direct_epilogue<ACT>;
     constexpr int NW = WAVES_M * WAVES_N;
@@ -779,9 +779,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_bf16_kernel(GemmAr
             for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j]));
     } else if constexpr (DIRECT) {
         static_assert(WTN == 64, "the direct epilogue pairs the four 16-column fragments of a 64-column wave tile");
-        gemm_epilogue_direct<WTM, REMAP, ACT, EPI>(p, acc, lane, m0, n0, wr, wc);
+        gemm_epilogue_direct<WTM, REMAP, ACT, EPI, 1, WHOLE>(p, acc, lane, m0, n0, wr, wc);
     } else {
-        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI>(p, acc, smem, wave, lane, m0, n0, wr, wc);
+        gemm_epilogue<WTM, WTN, REMAP, ACT, EPI, 1, WHOLE>(p, acc, smem, wave, lane, m0, n0, wr, wc);
     }
 }
 
@@ -1253,13 +1253,28 @@ hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
 template <int ACT>
 hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) { return launch_8phase2<false, ACT, EPI_GENERIC, true>(a, s); }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI, int WHOLE = 0>
 hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
+    // the static epilogue forms for whole tiles (as launch_8phase2), on the tile configurations the encoder stacks' remaining rows take
+    constexpr bool REST_CFG = (BM == 256 && BN == 128 && STAGGER) || (BM == 128 && BN == 128 && NSTAGE == 4) || (BM == 64 && BN == 128);
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && REST_CFG && !REMAP && (EPI == EPI_PLAIN || EPI == EPI_LS || EPI == EPI_FOLD)) {
+        if (a.M % BM == 0 && !a.mx_out_q) {
+            const int f = 1 | (a.res ? 2 : 0) | (a.stats_out ? 4 : 0) | (a.row_add ? 8 : 0);
+            if (f == 1) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI, 1>(a, s);
+            if constexpr (EPI != EPI_FOLD && ACT == ACT_NONE) {
+                if (f == 3) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI, 3>(a, s);
+                if (f == 7) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI, 7>(a, s);
+                if constexpr (EPI == EPI_PLAIN && !gemm_direct_epilogue<ACT>) {
+                    if (f == 15) return launch_cfg2<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI, 15>(a, s);
+                }
+            }
+        }
+    }
     constexpr int LDS = NSTAGE * (BM + BN) * ROW_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(LDS >= WM * WN * (BM / WM) * 128, "epilogue staging must fit in the stage ring");
     static_assert(!STAGGER || WM * WN == 8, "stagger pairs the two waves of each SIMD: 8-wave blocks only");
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, NSTAGE, STAGGER, REMAP, ACT, EPI, WHOLE>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
     if (hipError_t e = ensure_dynamic_lds((const void*)kern, LDS, attr_set); e != hipSuccess) return e;
     const int tilesM = (a.M + BM - 1) / BM, tilesN = a.N / BN;
