@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
     float* xq_lds = (float*)(smem + KV_BYTES);  // [slot][row][HD + 4]
 
     const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < NT);  // (the staging loops' `idx < 512` tests fold away where NT divides 512)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
