@@ -67,6 +67,29 @@ def test_gemv_forms(dev, N, K):
         assert torch.equal(fused, two)
 
 
+@pytest.mark.parametrize("norm,gated", [(False, False), (True, False), (True, True), (False, True)])
+def test_gemv_exact_and_general_instantiations_give_the_same_bits(dev, norm, gated):
+    """decode.hip picks an EXACT instantiation (no per-chunk clamps / selects) when K / 8 is a multiple of the trip and N of the block's
+    rows, the general one otherwise: the rows of a 4096 x 4096 launch (EXACT) must equal, bit for bit, the same rows computed as the head
+    of a 4098-row launch (general: 4098 is no multiple of the block's rows)."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    N, K = 4096, 4096
+    W = (torch.randn(N + 2, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    W2 = (torch.randn(N + 2, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    x = (torch.randn(K, generator=g) * 2).to(torch.bfloat16).to(dev)
+    wn = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).to(dev)
+    ya = torch.empty(N, dtype=torch.bfloat16, device=dev)
+    yb = torch.empty(N + 2, dtype=torch.bfloat16, device=dev)
+    w2a, w2b = (ptr(W2[:N]), ptr(W2)) if gated else (0, 0)
+    nw = ptr(wn) if norm else 0
+    check(lib.merv_decode_gemv(ptr(W[:N]), w2a, ptr(x), 0, ptr(ya), 0, N, K, nw, 1e-5, _st(dev)), "exact")
+    check(lib.merv_decode_gemv(ptr(W), w2b, ptr(x), 0, ptr(yb), 0, N + 2, K, nw, 1e-5, _st(dev)), "general")
+    assert torch.equal(ya, yb[:N])
+
+
 def test_gemv3_equals_three_gemvs(dev):
     from merv_amd import _lib
     from merv_amd._lib import check, ptr

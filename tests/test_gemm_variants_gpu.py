@@ -35,6 +35,31 @@ def test_variant(dev, variant, M, N, K):
     assert rel_l2(plain, a.float() @ w.float().t()) < 6e-3
 
 
+@pytest.mark.parametrize("act,ls,res", [("none", False, False), ("none", False, True), ("none", True, True), ("gelu_erf", False, False),
+                                        ("quick_gelu", False, False)])
+def test_static_and_run_time_epilogue_forms_give_the_same_bits(dev, act, ls, res):
+    """Whole-tile launches (M a multiple of the tile) take the static epilogue instantiations (gemm.hip, WHOLE: every optional term a template
+    flag), ragged ones the run-time form. The rows of a 65536-row problem (256 whole m-tiles: static, eight-phase kernel) must equal, bit for
+    bit, the same rows computed as the head of a 65537-row problem (the last tile ragged: run-time form for the rows the eight-phase kernel
+    takes when the split differs, small tiles for the rest) -- whichever kernel and form a row lands in."""
+    from merv_amd import ops
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 65536, 512, 256
+    a = torch.randn(M + 1, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * K**-0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    lscale = (0.5 + torch.rand(N, generator=g)).to(dev) if ls else None
+    x = torch.randn(M + 1, N, generator=g).to(torch.bfloat16).to(dev) if res else None
+    whole = ops.gemm(a[:M], w, bias=bias, act=act, lscale=lscale, res=None if x is None else x[:M])
+    ragged = ops.gemm(a, w, bias=bias, act=act, lscale=lscale, res=x)
+    assert torch.equal(whole, ragged[:M])
+    # a sub-round launch (few tiles: the eight-phase kernel takes the whole ragged problem in its run-time form) against the static form
+    Ms = 256 * 40
+    small_whole = ops.gemm(a[:Ms], w, bias=bias, act=act, lscale=lscale, res=None if x is None else x[:Ms])
+    small_ragged = ops.gemm(a[: Ms + 3], w, bias=bias, act=act, lscale=lscale, res=None if x is None else x[: Ms + 3])
+    assert torch.equal(small_whole, small_ragged[:Ms]) and torch.equal(small_whole, whole[:Ms])
+
+
 def test_split_launch_carries_row_offsets_of_optional_epilogue_inputs(dev):
     """A GEMM large enough for the round-filling split (eight-phase part + remaining rows): the folded-LayerNorm row
     statistics and the MXFP8 output of the SECOND launch must be offset by the rows the first one took."""
