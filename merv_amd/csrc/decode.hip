@@ -437,40 +437,50 @@ MERV_DEVICE void da_one(DaState& st, const float (&qf)[8], const float (&kf)[8],
     for (int i = 0; i < 8; ++i) st.o[i] = fmaf(st.o[i], a, e * vf[i]);
     st.m = mn;
 }
-// cache positions j0 + g, j0 + g + 16, ... < jc, DA_UN per trip: all K / V rows of a trip are requested before the first is
-// used, and the trip's scores share one running-max update (a trip per position left the kernel waiting for one HBM round
-// trip per position: 15 us per layer at 1050 positions for 17 MB of cache)
+// One trip of a 16-lane group: cache positions j, j + 16, ... (DA_UN of them) < jc. All K / V rows of a trip are requested before the
+// first is used, and the trip's scores share one running-max update (a trip per position left the kernel waiting for one HBM round
+// trip per position: 15 us per layer at 1050 positions for 17 MB of cache). da_request only issues the loads (past the range: a valid
+// row, masked in da_consume), so that a caller can have the next trip in flight while it multiplies this one.
+MERV_DEVICE void da_request(u32x4 (&kr)[DA_UN], u32x4 (&vr)[DA_UN], const bf16_t* Kc, const bf16_t* Vc, int j, int jc, int sub) {
+    const int jv = j < jc ? j : 0;
+#pragma unroll
+    for (int u = 0; u < DA_UN; ++u) {
+        const int ju = j + 16 * u < jc ? j + 16 * u : jv;
+        kr[u] = *(const u32x4*)(Kc + (size_t)ju * 128 + sub * 8);
+        vr[u] = *(const u32x4*)(Vc + (size_t)ju * 128 + sub * 8);
+    }
+}
+MERV_DEVICE void da_consume(DaState& st, const float (&qf)[8], const u32x4 (&kr)[DA_UN], const u32x4 (&vr)[DA_UN], int j, int jc, float sc) {  // j < jc
+    float d[DA_UN], mn = st.m;
+#pragma unroll
+    for (int u = 0; u < DA_UN; ++u) {
+        float kf[8];
+        unpack8f(kr[u], kf);
+        const float dd = da_dot16(qf, kf) * sc;  // (unconditional: the shuffles stay out of a branch; a masked row is a valid row)
+        d[u] = j + 16 * u < jc ? dd : -INFINITY;
+        mn = fmaxf(mn, d[u]);
+    }
+    const float a = __builtin_amdgcn_exp2f(st.m - mn);  // position j itself is in range: mn is finite
+    st.l *= a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st.o[i] *= a;
+#pragma unroll
+    for (int u = 0; u < DA_UN; ++u) {
+        const float e = __builtin_amdgcn_exp2f(d[u] - mn);
+        float vf[8];
+        unpack8f(vr[u], vf);
+        st.l += e;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.o[i] = fmaf(e, vf[i], st.o[i]);
+    }
+    st.m = mn;
+}
+// cache positions j0 + g, j0 + g + 16, ... < jc
 MERV_DEVICE void da_range(DaState& st, const float (&qf)[8], const bf16_t* Kc, const bf16_t* Vc, int j0, int jc, int g, int sub, float sc) {
     for (int j = j0 + g; j < jc; j += 16 * DA_UN) {
         u32x4 kr[DA_UN], vr[DA_UN];
-#pragma unroll
-        for (int u = 0; u < DA_UN; ++u) {
-            const int ju = j + 16 * u < jc ? j + 16 * u : j;  // past the range: a valid row, its score is masked below
-            kr[u] = *(const u32x4*)(Kc + (size_t)ju * 128 + sub * 8);
-            vr[u] = *(const u32x4*)(Vc + (size_t)ju * 128 + sub * 8);
-        }
-        float d[DA_UN], mn = st.m;
-#pragma unroll
-        for (int u = 0; u < DA_UN; ++u) {
-            float kf[8];
-            unpack8f(kr[u], kf);
-            d[u] = j + 16 * u < jc ? da_dot16(qf, kf) * sc : -INFINITY;
-            mn = fmaxf(mn, d[u]);
-        }
-        const float a = __builtin_amdgcn_exp2f(st.m - mn);  // position j itself is in range: mn is finite
-        st.l *= a;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) st.o[i] *= a;
-#pragma unroll
-        for (int u = 0; u < DA_UN; ++u) {
-            const float e = __builtin_amdgcn_exp2f(d[u] - mn);
-            float vf[8];
-            unpack8f(vr[u], vf);
-            st.l += e;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) st.o[i] = fmaf(e, vf[i], st.o[i]);
-        }
-        st.m = mn;
+        da_request(kr, vr, Kc, Vc, j, jc, sub);
+        da_consume(st, qf, kr, vr, j, jc, sc);
     }
 }
 
@@ -571,12 +581,28 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane >> 4, sub = lane & 15;
     const int g = wave * 4 + grp;
+    // Everything the block reads hangs on *pos alone, so all of it is requested at once (round 5; until then the launch was a chain of
+    // round trips: position -> tables / q -> first trip of cache rows -> ... -> the new token's k / v in the last range's block):
+    // the rotary tables' row, the head's raw q, the raw k / v of the token being decoded (used by ONE group of the last range, requested
+    // by all: 32 B per lane) and then the group's first trip of cache rows; the rotation of q runs while the cache rows are in flight.
+    bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
+    bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
+    const int jc = j1 < pos ? j1 : (int)pos;  // cached positions of this range end before the current token
+    const int ntrips = jc > j0 ? (jc - j0 + 16 * DA_UN - 1) / (16 * DA_UN) : 0;  // block-uniform (a group past its last row skips the multiply)
+    const u32x4 cosv = *(const u32x4*)(p.cos + pos * 128 + sub * 8);
+    const u32x4 sinv = *(const u32x4*)(p.sin + pos * 128 + sub * 8);
+    const u32x4 q_own = *(const u32x4*)(p.q + (h * 128 + sub * 8));
+    const u32x4 k_own = *(const u32x4*)(p.k + (hkv * 128 + sub * 8));
+    const u32x4 vraw = *(const u32x4*)(p.v + (hkv * 128 + sub * 8));
+    int j = j0 + g;
+    u32x4 kr[DA_UN], vr[DA_UN];
+    da_request(kr, vr, Kc, Vc, j, jc, sub);
+    __builtin_amdgcn_sched_barrier(0);
     // rotary at *pos: lane `sub` owns dims 8 sub .. 8 sub + 7, their rotate_half partners sit in lane sub ^ 8 of the group
     float cf[8], sf[8];
-    unpack8f(*(const u32x4*)(p.cos + pos * 128 + sub * 8), cf);
-    unpack8f(*(const u32x4*)(p.sin + pos * 128 + sub * 8), sf);
-    auto rotary = [&](const bf16_t* base, int off, int total, float (&r)[8]) {
-        const u32x4 own = *(const u32x4*)(base + (off + sub * 8));
+    unpack8f(cosv, cf);
+    unpack8f(sinv, sf);
+    auto rotary = [&](const u32x4& own, float (&r)[8]) {
         u32x4 oth;
 #pragma unroll
         for (int q = 0; q < 4; ++q) oth[q] = __shfl_xor(own[q], 8, 64);
@@ -588,26 +614,43 @@ MERV_DEVICE void attn_fused_body(const DecodeAttnFusedArgs& p, const int h, cons
         for (int i = 0; i < 8; ++i) r[i] = round_bf(round_bf(a[i] * cf[i]) + round_bf(sgn * b[i] * sf[i]));
     };
     float qf[8];
-    rotary(p.q, h * 128, p.H * 128, qf);
-    bf16_t* Kc = p.k_cache + (size_t)hkv * p.max_len * 128;
-    bf16_t* Vc = p.v_cache + (size_t)hkv * p.max_len * 128;
+    rotary(q_own, qf);
     DaState st;
     st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) st.o[i] = 0.f;
     const float sc = p.scale * 1.4426950408889634f;
-    da_range(st, qf, Kc, Vc, j0, j1 < pos ? j1 : (int)pos, g, sub, sc);  // cached positions of this range end before the current token
+    // trip t + 1 is requested (unconditionally: a request behind a branch would make every wait of the multiply a vmcnt(0)) before trip t
+    // is multiplied, into the other of two register sets (a copy would wait for the rows just requested); the last trip is multiplied
+    // without a request behind it, so that no wave ends with loads nobody uses
+    if (ntrips > 0) {
+        u32x4 kn[DA_UN], vn[DA_UN];
+        constexpr int TRIP = 16 * DA_UN;
+        for (int t = 0;; t += 2, j += 2 * TRIP) {
+            if (t + 1 >= ntrips) {
+                if (j < jc) da_consume(st, qf, kr, vr, j, jc, sc);
+                break;
+            }
+            da_request(kn, vn, Kc, Vc, j + TRIP, jc, sub);
+            if (j < jc) da_consume(st, qf, kr, vr, j, jc, sc);
+            if (t + 2 >= ntrips) {
+                if (j + TRIP < jc) da_consume(st, qf, kn, vn, j + TRIP, jc, sc);
+                break;
+            }
+            da_request(kr, vr, Kc, Vc, j + 2 * TRIP, jc, sub);
+            if (j + TRIP < jc) da_consume(st, qf, kn, vn, j + TRIP, jc, sc);
+        }
+    }
     if (pos >= j0 && pos < j1 && g == (int)((pos - j0) & 15)) {  // uniform per 16-lane group: the shuffles inside stay in the group
         float kf[8], vf[8];
-        rotary(p.k, hkv * 128, p.Hkv * 128, kf);
-        const u32x4 vraw = *(const u32x4*)(p.v + (hkv * 128 + sub * 8));
+        rotary(k_own, kf);
         unpack8f(vraw, vf);
         da_one(st, qf, kf, vf, sc);
         if (h % grp_heads == 0) {
-            u32x4 kr;
+            u32x4 kw;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) kr[q] = pack2bf(kf[2 * q], kf[2 * q + 1]);
-            *(u32x4*)(Kc + (size_t)pos * 128 + sub * 8) = kr;
+            for (int q = 0; q < 4; ++q) kw[q] = pack2bf(kf[2 * q], kf[2 * q + 1]);
+            *(u32x4*)(Kc + (size_t)pos * 128 + sub * 8) = kw;
             *(u32x4*)(Vc + (size_t)pos * 128 + sub * 8) = vraw;
         }
     }
