@@ -193,6 +193,24 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
         wrow[0][r] = p.W + (size_t)n * p.K;
         if constexpr (NW_MATS == 2) wrow[1][r] = p.W2 + (size_t)n * p.K;
     }
+    // bias / residual of the wave's rows: requested before the weight trips (read at the end they were one more memory round trip at the
+    // tail of every wave, i.e. of the launch)
+    // (unconditional, raw: an absent vector reads x[0] -- a line the launch reads anyway -- and is not used -- behind a branch, or converted here, hipcc
+    // waits for the value on the spot, a round trip BEFORE the first weight request)
+    // Only in the launches without a fused norm (o / down projection, lm_head): the q / k / v launch has neither vector in the Llama
+    // family, and two more registers took it from six waves per SIMD to five (80 -> 83 VGPRs: +0.5 us).
+    constexpr bool PRE_ADD = NW_MATS == 1 && !NORM;
+    bf16_t biasv[GEMV_ROWS], resv[GEMV_ROWS];
+    if constexpr (PRE_ADD) {
+        const bf16_t* bias_p = p.bias ? p.bias : p.x;
+        const bf16_t* res_p = p.res ? p.res : p.x;
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r) {
+            const int n = n0 + r < p.N ? n0 + r : p.N - 1;
+            biasv[r] = bias_p[p.bias ? n : 0];
+            resv[r] = res_p[p.res ? n : 0];
+        }
+    }
     // UN chunks per lane per trip: UN x ROWS x NW_MATS weight loads of 16 B (and, without a norm, the x chunks they meet) are in
     // flight per lane before the first use. Every trip is a full batch: chunks past the row's end are clamped to a valid
     // address and meet x = 0 (a remainder loop of single loads costs one memory round trip per iteration: 3 us of the
@@ -303,13 +321,13 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
         for (int r = 0; r < GEMV_ROWS; ++r) {
             const int n = n0 + r;
             if (n >= p.N) break;
-            float v = round_bf(NW_MATS == 1 && p.bias ? acc[0][r] + bf2f(p.bias[n]) : acc[0][r]);  // the nn.Linear output as a bf16 tensor
+            float v = round_bf(NW_MATS == 1 && p.bias ? acc[0][r] + bf2f(PRE_ADD ? biasv[r] : p.bias[n]) : acc[0][r]);  // the nn.Linear output as a bf16 tensor
             if constexpr (NW_MATS == 2) {
                 const float g = v;
                 const float s = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor
                 v = s * round_bf(acc[1][r]);
             } else if (p.res) {
-                v = v + bf2f(p.res[n]);  // x + linear(...), rounded once more below
+                v = v + bf2f(PRE_ADD ? resv[r] : p.res[n]);  // x + linear(...), rounded once more below
             }
             if (p.y32) p.y32[n] = v;  // logits: .float() of the bf16 linear output
             else p.y[n] = f2bf(v);
@@ -818,6 +836,10 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
             for (int r = 0; r < OM_ROWS; ++r) wv[r][u] = __builtin_nontemporal_load((const u32x4*)(wrow[r] + cu * 8));
         }
     };
+    bf16_t resv[OM_ROWS];  // requested before the weights (as gemv_body: raw, unconditional; not one more round trip at the tail)
+    const bf16_t* res_p = p.res ? p.res : p.W;  // (absent: any valid address; the decoder always passes the residual)
+#pragma unroll
+    for (int r = 0; r < OM_ROWS; ++r) resv[r] = res_p[p.res ? (EXACT || n0 + r < p.N ? n0 + r : p.N - 1) : 0];
     int c = lane;
     issue_w(c);
     // merge: 8 consecutive values per thread, all of head (8 t) / 128
@@ -896,7 +918,7 @@ __global__ __launch_bounds__(OM_WAVES * 64) void oproj_merge_kernel(DecodeOprojM
             const int n = n0 + r;
             if (n >= p.N) break;
             float v = round_bf(acc[r]);                 // the nn.Linear output as a bf16 tensor
-            if (p.res) v = v + bf2f(p.res[n]);          // x + o_proj(...), rounded once more below
+            if (p.res) v = v + bf2f(resv[r]);           // x + o_proj(...), rounded once more below
             p.y[n] = f2bf(v);
         }
     }
