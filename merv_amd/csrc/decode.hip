@@ -344,6 +344,142 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
     gemv_body<NW_MATS, UN, NORM, GEMV_ROWS, EXACT>(p, blockIdx.x, lds, (u32x4*)gemv_dyn_lds);
 }
 
+// GEMV, one row per wave, with (a) the block's x -- copied, or RMS-normalised as in gemv_body -- ONCE in an LDS image: in gemv_body's plain
+// launches the x chunks are half of a lane's global loads (L2 hits, but the same queue and as many registers per trip as the weights) --
+// and (b) the wave's WHOLE row(s) requested up front (TRIPS x UN chunks per lane and matrix, no loop) and multiplied chunk by chunk: with
+// one trip in flight at a time a wave of the K = 11008 projection had nothing outstanding while it multiplied (8 waves per CU: 5.3 TB/s
+// against 5.9-6.8 for the K = 4096 launches), and left to itself hipcc converts every chunk to fp32 ahead of the serial multiply-add
+// chain (330 registers, one wave per SIMD). A lane multiplies its chunks in gemv_body's order (lane, lane + 64, ...), the norm and the
+// epilogue are gemv_body's: same bits. Rows of 64 (UN TRIPS - 1) < K / 8 <= 64 UN TRIPS chunks (only a lane's last chunk can lie past the
+// end: every other load is base + immediate offset); NORM: K <= 8192.
+template <int UN, int TRIPS, int NW_MATS, bool NORM>
+__global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char gemv_dyn_lds[];
+    __shared__ GemvLds lds;
+    u32x4* x_lds = (u32x4*)gemv_dyn_lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int n0 = blockIdx.x * GEMV_WAVES + wave;
+    if constexpr (NW_MATS == 1) {  // several matrices in one launch (q / k / v), as gemv_body
+        if (n0 >= p.N && p.Nb > 0) {
+            n0 -= p.N;
+            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }
+            else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; p.bias = p.bias_c; }
+        }
+    }
+    const bool idle = n0 >= p.N;  // (takes part in the block's image, then leaves)
+    const int n = idle ? p.N - 1 : n0;
+    const int nchunk = p.K >> 3;
+    const bf16_t* wrow[NW_MATS];
+    wrow[0] = p.W + (size_t)n * p.K;
+    if constexpr (NW_MATS == 2) wrow[1] = p.W2 + (size_t)n * p.K;
+    // bias / residual: raw, unconditional, before everything else (gemv_body)
+    const bf16_t biasv = (p.bias ? p.bias : p.x)[p.bias ? n : 0], resv = (p.res ? p.res : p.x)[p.res ? n : 0];
+    constexpr int XI = NORM ? 4 : (64 * UN * TRIPS + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);
+    u32x4 xi[XI], nw[NORM ? 4 : 1];
+    if constexpr (NORM) {
+        sumsq_request(p.x, nchunk, lane, wave, xi);  // thread t: chunks t + 256 i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = lane + 64 * wave + 256 * i;
+            nw[i] = cc < nchunk ? *(const u32x4*)(p.norm_w + cc * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int cc = (int)threadIdx.x + GEMV_WAVES * 64 * i;
+            xi[i] = *(const u32x4*)(p.x + (cc < nchunk ? cc : 0) * 8);
+        }
+    }
+    u32x4 wv[NW_MATS][TRIPS][UN];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int cu = lane + 64 * (t * UN + u);
+            const int cv = t * UN + u < UN * TRIPS - 1 || cu < nchunk ? cu : lane;
+#pragma unroll
+            for (int m = 0; m < NW_MATS; ++m) wv[m][t][u] = __builtin_nontemporal_load((const u32x4*)(wrow[m] + cv * 8));
+        }
+    __builtin_amdgcn_sched_barrier(0);  // everything is requested before anything waits
+    if constexpr (NORM) {
+        float ss = 0.f;  // sumsq_finish for K <= 8192 (no load inside)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float f[8];
+            unpack8f(xi[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+        }
+        ss = wave_sum64(ss);
+        if (lane == 0) lds.norm_part[wave] = ss;
+        __syncthreads();
+        const float rstd = rsqrtf((((lds.norm_part[0] + lds.norm_part[1]) + lds.norm_part[2]) + lds.norm_part[3]) / (float)p.K + p.norm_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = lane + 64 * wave + 256 * i;
+            if (cc < nchunk) {
+                float xf[8], wn[8];
+                unpack8f(xi[i], xf);
+                unpack8f(nw[i], wn);
+                u32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)  // weight * hidden.to(bf16): two roundings, as the module
+                    o[q] = pack2bf(wn[2 * q] * round_bf(xf[2 * q] * rstd), wn[2 * q + 1] * round_bf(xf[2 * q + 1] * rstd));
+                x_lds[cc] = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int cc = (int)threadIdx.x + GEMV_WAVES * 64 * i;
+            if (cc < nchunk) x_lds[cc] = xi[i];
+        }
+    }
+    __syncthreads();
+    if (idle) return;
+    float acc[NW_MATS];
+#pragma unroll
+    for (int m = 0; m < NW_MATS; ++m) acc[m] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int cu = lane + 64 * (t * UN + u);
+            const bool past = t * UN + u == UN * TRIPS - 1 && cu >= nchunk;
+            float xf[8];
+            unpack8f(x_lds[past ? lane : cu], xf);
+            if (past) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < NW_MATS; ++m) {
+                float wf[8];
+                unpack8f(wv[m][t][u], wf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[m] = fmaf(wf[j], xf[j], acc[m]);
+            }
+            // (the next chunk's LDS read and conversions stay behind this chunk's sums)
+            if constexpr (NW_MATS == 2) asm volatile("" : "+v"(acc[0]), "+v"(acc[1])::"memory");
+            else asm volatile("" : "+v"(acc[0])::"memory");
+        }
+#pragma unroll
+    for (int m = 0; m < NW_MATS; ++m) acc[m] = wave_sum64(acc[m]);
+    if (lane == 0) {
+        float v = round_bf(NW_MATS == 1 && p.bias ? acc[0] + bf2f(biasv) : acc[0]);  // the nn.Linear output as a bf16 tensor
+        if constexpr (NW_MATS == 2) {
+            const float g = v;
+            const float sg = round_bf(g / (1.f + __expf(-g)));  // F.silu on a bf16 tensor
+            v = sg * round_bf(acc[1]);
+        } else if (p.res) {
+            v = v + bf2f(resv);  // x + linear(...), rounded once more below
+        }
+        if (p.y32) p.y32[n] = v;
+        else p.y[n] = f2bf(v);
+    }
+}
+
 // ---- rotary embedding of q and k at the current position + cache update ----
 // q [H * hd], k [Hkv * hd], v [Hkv * hd] bf16; cos / sin tables [max_len, hd] bf16 (HF: emb = cat(freqs, freqs));
 // caches [Hkv, max_len, hd]. q_embed = q * cos + rotate_half(q) * sin with bf16 rounding of each product and of the sum.
@@ -1023,6 +1159,29 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     if (hooked) {
         const int r = c[0] - '0', u = c[1] - '0';
         if ((r == 2 && u == 4) || (r == 1 && (u == 4 || u == 8))) { rows = r; un = u; }
+    }
+    // Launches whose row is one trip of 8 chunks per lane (K = 4096) or two of 11 (K = 11008: down projection) take the x-in-LDS,
+    // whole-row-in-flight form (round 5, tools/sessions/gpu_r5_gemv_xlds.sh): the plain launches of <= 16384 rows (down 18.5 -> 16.9 us,
+    // plain o 7.8 -> 7.3) and the gate-up pair (30.3 -> 29.4); q / k / v with the fused norm measured 18.3 -> 18.6 and stays on gemv_body,
+    // lm_head is a tie. MERV_GEMV_XLDS (probe hook): "0" never, "1" the plain launches only, "2" plain launches of any size, "3" the
+    // default, "4" every launch the form fits.
+    static const char* xlds = getenv("MERV_GEMV_XLDS");
+    const char xmode = xlds && xlds[0] ? xlds[0] : '3';
+    const bool xplain = !a.W2 && !a.norm_w;
+    const bool xsize = rows_total <= 16384 || xmode == '4' || (xmode == '2' && xplain);
+    const bool xclass = xplain ? xmode >= '1' : a.W2 ? xmode >= '3' : xmode >= '4';
+    if (!hooked && xsize && xclass && (!a.norm_w || a.K <= 8192)) {
+        const dim3 grid((unsigned)((rows_total + GEMV_WAVES - 1) / GEMV_WAVES)), blk(GEMV_WAVES * 64);
+        const int nchunk = a.K >> 3;
+        const bool one = nchunk > 448 && nchunk <= 512, two = nchunk > 1344 && nchunk <= 1408 && xplain;
+        if (one || two) {
+            if (two) hipLaunchKernelGGL((gemv_xlds_kernel<11, 2, 1, false>), grid, blk, 2 * a.K, s, a);
+            else if (a.W2 && a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 2, true>), grid, blk, 2 * a.K, s, a);
+            else if (a.W2) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 2, false>), grid, blk, 2 * a.K, s, a);
+            else if (a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 1, true>), grid, blk, 2 * a.K, s, a);
+            else hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 1, false>), grid, blk, 2 * a.K, s, a);
+            return hipGetLastError();
+        }
     }
     if (rows == 1 && un == 8 && !hooked && !a.W2 && !a.norm_w) {
         // a trip is 64 lanes x UN chunks and the last one is padded with clamped (wasted) loads: K = 11008 is 1376 chunks = 3 trips
