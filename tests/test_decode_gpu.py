@@ -577,3 +577,23 @@ def test_generate_uses_hip_decoder_when_it_can(dev):
     emb2 = emb.repeat(2, 1, 1)  # batch 2: the PyTorch decoder
     llm.generate_from_embeds(emb2, max_new_tokens=3)
     assert not isinstance(next(iter(llm._decoders.values())), HipDecoder)
+
+
+def test_gemv_forms_give_the_same_bits_across_processes(dev):
+    """launch_decode_gemv picks between gemv_body and the x-in-LDS, whole-row-in-flight kernels by shape (MERV_GEMV_XLDS: probe hook read
+    once per process): 15 launches -- plain, fused norm, gate-up pair, q / k / v, ragged rows and K -- must give the same bits with the
+    form switched off ("0"), at its default and forced wherever it fits ("4")."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "", "4"):
+        env = dict(os.environ)
+        env.pop("MERV_GEMV_XLDS", None)
+        if mode:
+            env["MERV_GEMV_XLDS"] = mode
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "gemv_bits.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 15, r.stdout
+        outs.append(lines)
+    assert outs[0] == outs[1] == outs[2]
