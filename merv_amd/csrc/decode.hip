@@ -10,6 +10,7 @@
 //   rmsnorm_kernel         y = w * bf16(x * rsqrt(mean(x^2) + eps))                    (LlamaRMSNorm.forward)
 //   gemv_kernel            y = bf16(W x) [+ residual]      W [N, K] bf16 streamed once (nn.Linear, M = 1)
 //   gemv_silu_mul_kernel   y = bf16(silu(bf16(Wg x))) * bf16(Wu x)                      (LlamaMLP: act_fn(gate) * up)
+//   gemv_xlds_kernel       the same two, one row per wave: x once per block in LDS, the whole row in flight (round 5; plain launches + gate-up pair)
 //   rope_cache_kernel      q, k <- rotary(pos); K / V cache[pos] <- k, v              (apply_rotary_pos_emb + cache update)
 //   decode_attn_kernel     one query per head against cache[0 .. pos], split over positions, (m, l, o) partials
 //   decode_attn_merge_kernel  merges the partials                                      (flash-decoding)
