@@ -353,7 +353,9 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_kernel(DecodeGemvArgs p)
 // chain (330 registers, one wave per SIMD). A lane multiplies its chunks in gemv_body's order (lane, lane + 64, ...), the norm and the
 // epilogue are gemv_body's: same bits. Rows of 64 (UN TRIPS - 1) < K / 8 <= 64 UN TRIPS chunks (only a lane's last chunk can lie past the
 // end: every other load is base + immediate offset); NORM: K <= 8192.
-template <int UN, int TRIPS, int NW_MATS, bool NORM>
+// NXI (fused norm): chunks per thread of the norm's pass over x -- 2 for K <= 4096 (the chunks 512.. of sumsq_request's four are zeros there
+// and add exactly nothing: skipping them leaves the bits and frees 24 registers), 4 up to K = 8192
+template <int UN, int TRIPS, int NW_MATS, bool NORM, int NXI = 4>
 __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char gemv_dyn_lds[];
     __shared__ GemvLds lds;
@@ -376,13 +378,13 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvAr
     if constexpr (NW_MATS == 2) wrow[1] = p.W2 + (size_t)n * p.K;
     // bias / residual: raw, unconditional, before everything else (gemv_body)
     const bf16_t biasv = (p.bias ? p.bias : p.x)[p.bias ? n : 0], resv = (p.res ? p.res : p.x)[p.res ? n : 0];
-    constexpr int XI = NORM ? 4 : (64 * UN * TRIPS + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);
-    u32x4 xi[XI], nw[NORM ? 4 : 1];
+    constexpr int XI = NORM ? NXI : (64 * UN * TRIPS + GEMV_WAVES * 64 - 1) / (GEMV_WAVES * 64);
+    u32x4 xi[XI], nw[NORM ? NXI : 1];
     if constexpr (NORM) {
-        sumsq_request(p.x, nchunk, lane, wave, xi);  // thread t: chunks t + 256 i
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NXI; ++i) {  // sumsq_request's chunks (thread t: t + 256 i) and their norm weights
             const int cc = lane + 64 * wave + 256 * i;
+            xi[i] = cc < nchunk ? *(const u32x4*)(p.x + cc * 8) : u32x4{0u, 0u, 0u, 0u};  // (a zero chunk adds exactly nothing)
             nw[i] = cc < nchunk ? *(const u32x4*)(p.norm_w + cc * 8) : u32x4{0u, 0u, 0u, 0u};
         }
     } else {
@@ -406,18 +408,19 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvAr
     if constexpr (NORM) {
         float ss = 0.f;  // sumsq_finish for K <= 8192 (no load inside)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NXI; ++i) {
             float f[8];
             unpack8f(xi[i], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
+            asm volatile("" : "+v"(ss));
         }
         ss = wave_sum64(ss);
         if (lane == 0) lds.norm_part[wave] = ss;
         __syncthreads();
         const float rstd = rsqrtf((((lds.norm_part[0] + lds.norm_part[1]) + lds.norm_part[2]) + lds.norm_part[3]) / (float)p.K + p.norm_eps);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NXI; ++i) {
             const int cc = lane + 64 * wave + 256 * i;
             if (cc < nchunk) {
                 float xf[8], wn[8];
@@ -429,6 +432,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvAr
                     o[q] = pack2bf(wn[2 * q] * round_bf(xf[2 * q] * rstd), wn[2 * q + 1] * round_bf(xf[2 * q + 1] * rstd));
                 x_lds[cc] = o;
             }
+            asm volatile("" ::: "memory");  // chunk by chunk (registers: see the multiply below)
         }
     } else {
 #pragma unroll
@@ -1177,9 +1181,9 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
         const bool one = nchunk > 448 && nchunk <= 512, two = nchunk > 1344 && nchunk <= 1408 && xplain;
         if (one || two) {
             if (two) hipLaunchKernelGGL((gemv_xlds_kernel<11, 2, 1, false>), grid, blk, 2 * a.K, s, a);
-            else if (a.W2 && a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 2, true>), grid, blk, 2 * a.K, s, a);
+            else if (a.W2 && a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 2, true, 2>), grid, blk, 2 * a.K, s, a);  // (K <= 4096 here)
             else if (a.W2) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 2, false>), grid, blk, 2 * a.K, s, a);
-            else if (a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 1, true>), grid, blk, 2 * a.K, s, a);
+            else if (a.norm_w) hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 1, true, 2>), grid, blk, 2 * a.K, s, a);
             else hipLaunchKernelGGL((gemv_xlds_kernel<8, 1, 1, false>), grid, blk, 2 * a.K, s, a);
             return hipGetLastError();
         }
