@@ -173,7 +173,7 @@ MERV_DEVICE void gemv_body(DecodeGemvArgs p, const int block, GemvLds& lds, u32x
     if constexpr (NW_MATS == 1) {
         if (n0 >= p.N && p.Nb > 0) {
             n0 -= p.N;
-            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }
+            if (n0 < p.Nb || p.Nc <= 0) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }  // (two matrices: rows past the end idle on the second)
             else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; p.bias = p.bias_c; }
         }
     }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(GEMV_WAVES * 64) void gemv_xlds_kernel(DecodeGemvAr
     if constexpr (NW_MATS == 1) {  // several matrices in one launch (q / k / v), as gemv_body
         if (n0 >= p.N && p.Nb > 0) {
             n0 -= p.N;
-            if (n0 < p.Nb) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }
+            if (n0 < p.Nb || p.Nc <= 0) { p.W = p.Wb; p.y = p.yb; p.N = p.Nb; p.bias = p.bias_b; }  // (two matrices: rows past the end idle on the second)
             else { n0 -= p.Nb; p.W = p.Wc; p.y = p.yc; p.N = p.Nc; p.bias = p.bias_c; }
         }
     }
