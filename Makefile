@@ -7,7 +7,11 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 HIP_SRCS := $(CSRC)/gemm.hip $(CSRC)/attention.hip $(CSRC)/rowops.hip $(CSRC)/preproc.hip $(CSRC)/backward.hip $(CSRC)/mxfp8.hip $(CSRC)/decode.hip $(CSRC)/capi.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 
-all: lib oracle
+HOOKS_LIB := merv_amd/lib/libmerv_hip_hooks.so
+HOOKS_DIR := build/hooks
+HOOKS_OBJS := $(patsubst $(CSRC)/%.hip,$(HOOKS_DIR)/%.o,$(HIP_SRCS))
+
+all: lib hooks oracle
 
 lib: $(LIB)
 
@@ -24,11 +28,24 @@ $(LIB): $(HIP_OBJS) $(CSRC)/sampler.o $(CSRC)/prof.o
 	@mkdir -p merv_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
+# The same sources with the tuning hooks compiled in (-DMERV_TUNING_HOOKS: the MERV_* tuning variables are read, merv_debug_set_* work):
+# test / probe infrastructure, loaded only under MERV_TUNING_HOOKS=1 (merv_amd/_lib.py). The product library above has none of it.
+hooks: $(HOOKS_LIB)
+
+$(HOOKS_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h $(CSRC)/prof.h include/merv_hip.h
+	@mkdir -p $(HOOKS_DIR)
+	$(HIPCC) $(HIPFLAGS) -DMERV_TUNING_HOOKS -c $< -o $@
+
+$(HOOKS_LIB): $(HOOKS_OBJS) $(CSRC)/sampler.o $(CSRC)/prof.o
+	@mkdir -p merv_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(CSRC)/*.o $(LIB)
+	rm -f $(CSRC)/*.o $(LIB) $(HOOKS_LIB)
+	rm -rf $(HOOKS_DIR)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib hooks oracle clean

@@ -31,6 +31,40 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+
+
+def _self_spawn_ranks() -> None:
+    """`python3 bench.py --gpus N` (N > 1) without an outer launcher: start the ranks here. Runs BEFORE torch is imported and before any
+    GPU call (a process that has initialised the GPU must not exec, and this one never does): the launcher is a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port> bench.py <same args>`), its stdout -- rank
+    0's ONE JSON line -- and stderr pass straight through, and this process exits with its return code. Under an outer launcher
+    (WORLD_SIZE set: how the driver starts N > 1) nothing happens here. MERV_BENCH_FORCE_DISTRIBUTED=1 takes the same route at N = 1 (the
+    N > 1 code path on one GPU: an RCCL process group of one rank)."""
+    if "WORLD_SIZE" in os.environ or "-h" in sys.argv or "--help" in sys.argv:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:], 1):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    force = os.environ.get("MERV_BENCH_FORCE_DISTRIBUTED") == "1" and os.environ.get("MERV_BENCH_SELF_SPAWN", "1") != "0"
+    if n <= 1 and not force:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as so:  # a free rendezvous port on the loopback interface (the container hostname may not resolve)
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(n, 1)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench] no outer launcher (WORLD_SIZE unset): starting {max(n, 1)} rank(s) as a child process: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=dict(os.environ)).returncode)
+
+
+if __name__ == "__main__":
+    _self_spawn_ranks()
+
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
@@ -293,8 +327,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1:  # (python3 bench.py --gpus N starts its own ranks in _self_spawn_ranks(); this is an import-and-call misuse)
+            raise SystemExit("bench.py --gpus N>1: WORLD_SIZE is 1 -- run `python3 bench.py --gpus N` or launch with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the HIP path has no CPU fallback")
@@ -315,8 +349,8 @@ def main():
 
     from merv_amd import _lib
     lib = _lib.load()
-    if os.environ.get("MERV_GEMM_GROUP_M"):  # tuning hook: tile-order group size of every GEMM launch
-        lib.merv_debug_set_gemm_variant(int(os.environ["MERV_GEMM_GROUP_M"]) << 8)
+    if _lib.tuning("MERV_GEMM_GROUP_M"):  # tuning hook (MERV_TUNING_HOOKS=1 only: the hooks build): tile-order group size of every GEMM launch
+        lib.merv_debug_set_gemm_variant(int(_lib.tuning("MERV_GEMM_GROUP_M")) << 8)
     single = world == 1 and not force_dist
     # rank 0 runs the roofline / parity / cpu_baseline legs at every N (its own GPU, its own videos; the other ranks wait at the
     # barrier below), so a multi-GPU line carries them too; the e2e leg (a 7B LLM beside the encoders) stays an N = 1 leg

@@ -29,8 +29,9 @@ extern "C" {
 
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
- *    section 5) are no longer exported; every other entry point unchanged */
-#define MERV_ABI_VERSION 3
+ *    section 5) are no longer exported; every other entry point unchanged
+ * 4 (round 6): merv_tuning_hooks added; the product build reads no environment variable and merv_debug_set_* are no-ops in it */
+#define MERV_ABI_VERSION 4
 
 /* activation kinds */
 enum { MERV_ACT_NONE = 0, MERV_ACT_GELU_ERF = 1, MERV_ACT_GELU_TANH = 2, MERV_ACT_QUICK_GELU = 3 };
@@ -280,11 +281,15 @@ int merv_preprocess_pil(const void *frames_u8, int32_t T, int32_t H, int32_t W, 
 int merv_preprocess_languagebind(const void *frames_u8, int32_t T, int32_t H, int32_t W, int32_t out_size, int32_t flip,
                                  const float *mean3, const float *std3, void *out_pixels, int32_t out_dtype, void *stream);
 
-/* Tuning / test hook: force the GEMM tile configuration (low byte: 0 auto, 1: 128x128 two-deep ring, 3: 256x128,
+/* 1 when this build of the library has its tuning hooks compiled in (-DMERV_TUNING_HOOKS: merv_amd/lib/libmerv_hip_hooks.so, the test /
+ * probe build of the same sources), 0 for the product library: that one reads no environment variable and keeps no process-global
+ * switch -- kernel selection is a function of a call's arguments alone -- and the two setters below are no-ops in it. */
+int merv_tuning_hooks(void);
+/* Tuning / test hook (hooks build only): force the GEMM tile configuration (low byte: 0 auto, 1: 128x128 two-deep ring, 3: 256x128,
  * 4: 256x128 with staggered half-blocks, 6: 128x128 four-deep ring, 7: 256x256 eight-phase where the shape allows it;
  * second byte: tile-order group size, 0 = default). */
 void merv_debug_set_gemm_variant(int32_t variant);
-/* Tuning / test hook: the attention kernels' deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to
+/* Tuning / test hook (hooks build only): the attention kernels' deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to
  * 2^thr before its softmax reference moves); 0 = exact running maximum, default 8, values outside [0, 64] restore the default. */
 void merv_debug_set_attn_rescale_thr(float thr);
 /* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */

@@ -16,6 +16,20 @@ from pathlib import Path
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmerv_hip.so"
+# the test / probe build of the same sources (-DMERV_TUNING_HOOKS, `make hooks`): loaded instead of the product library only when
+# MERV_TUNING_HOOKS=1 is set. The product library reads no environment variable (no hidden global state).
+HOOKS_LIB_PATH = LIB_PATH.with_name("libmerv_hip_hooks.so")
+
+
+def tuning_hooks_enabled() -> bool:
+    return os.environ.get("MERV_TUNING_HOOKS") == "1"
+
+
+def tuning(name: str, default=None):
+    """A MERV_* tuning / A-B variable -- honoured only under MERV_TUNING_HOOKS=1 (tests, tools/probes); otherwise `default`: a host
+    process's environment does not change what the product path runs."""
+    return os.environ.get(name, default) if tuning_hooks_enabled() else default
+
 
 ACT = {"none": 0, "gelu_erf": 1, "gelu_tanh": 2, "quick_gelu": 3}
 PIX_LAYOUT = {"BFCHW": 0, "BCFHW": 1}
@@ -54,7 +68,7 @@ class EncoderWeights(C.Structure):
 _i32, _i64, _f32, _f64, _vp, _sz = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
 
-ABI_VERSION = 3  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
+ABI_VERSION = 4  # include/merv_hip.h MERV_ABI_VERSION this binding was written against
 
 SIGNATURES = {
     "merv_last_error": (C.c_char_p, []),
@@ -117,6 +131,7 @@ SIGNATURES = {
     "merv_decode_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_oproj_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_decode_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _vp]),
+    "merv_tuning_hooks": (C.c_int, []),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_debug_set_attn_rescale_thr": (None, [_f32]),
     "merv_prof_enable": (None, [_i32]),
@@ -132,16 +147,17 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = Path(os.environ.get("MERV_HIP_LIB", LIB_PATH))
+    path = Path(os.environ.get("MERV_HIP_LIB", HOOKS_LIB_PATH if tuning_hooks_enabled() else LIB_PATH))
     if not path.exists():
         raise RuntimeError(
-            f"libmerv_hip.so not found at {path}: build it with `make lib` (or __graft_entry__.build()). "
+            f"{path.name} not found at {path}: build it with `make lib hooks` (or __graft_entry__.build()). "
             "merv_amd has no CPU fallback."
         )
     lib = C.CDLL(str(path))
-    # MERV_HIP_LIB names another build for same-box A/B pairs (tools/probes/ab_*.sh), possibly a previous round's: symbols that
-    # library lacks stay unbound (using one raises) and its ABI version is only reported. The product library is checked strictly.
-    ab_build = "MERV_HIP_LIB" in os.environ
+    # MERV_HIP_LIB is the ordinary library-path override and is checked as strictly as the in-tree build (every ABI symbol, the ABI
+    # version). Only with MERV_HIP_LIB_AB=1 beside it (same-box A/B pairs against a previous round's build, tools/probes/ab_*.sh) do
+    # symbols that library lacks stay unbound (using one raises) and is its ABI version only reported.
+    ab_build = "MERV_HIP_LIB" in os.environ and os.environ.get("MERV_HIP_LIB_AB") == "1"
     for name, (res, args) in SIGNATURES.items():
         if ab_build and not hasattr(lib, name):
             print(f"[merv_amd] A/B library {path} does not export {name}", file=sys.stderr)

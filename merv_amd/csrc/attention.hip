@@ -986,16 +986,18 @@ __global__ __launch_bounds__(NH > 4 ? NH * 64 : 256) void temporal_attn_kernel(T
 }  // namespace
 
 static float initial_rescale_thr() {
-    const char* e = getenv("MERV_ATTN_RESCALE_THR");
+    const char* e = merv_tuning_env("MERV_ATTN_RESCALE_THR");
     const float v = e ? (float)atof(e) : 8.0f;
     return (v >= 0.f && v <= 64.f) ? v : 8.0f;
 }
 static std::atomic<float> g_attn_rescale_thr{initial_rescale_thr()};
-void set_attn_rescale_thr(float thr) { g_attn_rescale_thr.store((thr >= 0.f && thr <= 64.f) ? thr : 8.0f, std::memory_order_relaxed); }
+void set_attn_rescale_thr(float thr) {  // (product build: a no-op -- see merv_tuning_env, common.h)
+    if constexpr (MERV_HOOKS) g_attn_rescale_thr.store((thr >= 0.f && thr <= 64.f) ? thr : 8.0f, std::memory_order_relaxed);
+}
 
 // MERV_ATTN_VTR=0 in the environment selects the transposing-store V path (diagnostic switch, re-read per launch).
 static bool use_vtr() {
-    const char* e = getenv("MERV_ATTN_VTR");
+    const char* e = merv_tuning_env("MERV_ATTN_VTR");
     return !(e && e[0] == '0');
 }
 
@@ -1027,7 +1029,7 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     // more padded tiles, because with two tiles per wave both score products are issued before the first softmax, so
     // the matrix pipe works under the softmax VALU stream (measured at B=8: 354 us vs 440-463 us per layer with 3 x 3).
     const int t32 = (a.L + 31) / 32;
-    static const char* force = getenv("MERV_ATTN_CFG");  // tuning hook: "33" or "42"
+    static const char* force = merv_tuning_env("MERV_ATTN_CFG");  // tuning hook: "33" or "42"
     if (force && force[0] == '3') return launch_attn_cfg<3, 3>(a, s);
     if (force && force[0] == '4') return launch_attn_cfg<4, 2>(a, s);
     if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
@@ -1060,7 +1062,7 @@ hipError_t launch_temporal_attention(const TemporalAttnArgs& a, hipStream_t s) {
     if (a.t != 8 || a.D != a.heads * HD) return hipErrorInvalidValue;
     const int NP = a.nclips * a.ntok;
     ProfScope ps(PROF_TATTN, s, 4.0 * NP * 64.0 * a.D, 2.0 * 4.0 * NP * 8.0 * a.D);
-    static const char* force = getenv("MERV_TATTN_NH");  // tuning hook: heads per block 1 / 4 / 8
+    static const char* force = merv_tuning_env("MERV_TATTN_NH");  // tuning hook: heads per block 1 / 4 / 8
     int nh = a.heads % 8 == 0 ? 8 : (a.heads % 4 == 0 ? 4 : 1);  // 16 videos: 122 / 113.5 / 111 us per layer with 1 / 4 / 8 heads per block
     if (force && (force[0] == '1' || (force[0] == '4' && a.heads % 4 == 0) || (force[0] == '8' && a.heads % 8 == 0))) nh = force[0] - '0';
     auto go = [&](auto nh_tag) {

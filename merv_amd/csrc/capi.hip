@@ -385,12 +385,12 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
         return launch_row_stats(rs, s);
     };
     // does a folded LayerNorm read x right after the GEMM that writes it here? (then that GEMM produces the partials)
-    static const bool fused_stats = !(getenv("MERV_LN_FUSED_STATS") && getenv("MERV_LN_FUSED_STATS")[0] == '0');  // A/B hook
+    static const bool fused_stats = !(merv_tuning_env("MERV_LN_FUSED_STATS") && merv_tuning_env("MERV_LN_FUSED_STATS")[0] == '0');  // A/B hook
     const bool fold_qkv = e->fold && !mx_qkv && fused_stats, fold_fc1 = e->fold && !mx_fc1 && fused_stats;
     // LanguageBind: the temporal LayerNorm of blocks 1 .. folds into the temporal qkv GEMM as well -- the previous block's fc2 epilogue
     // adds this block's temporal embedding into x (GemmArgs::row_add) and leaves the statistics partials, so no kernel re-reads x.
     // Block 0 keeps the LayerNorm kernel (its x comes from the embedding / pre-LayerNorm).
-    static const bool fold_t_env = !(getenv("MERV_LN_FOLD_TEMPORAL") && getenv("MERV_LN_FOLD_TEMPORAL")[0] == '0');  // A/B hook
+    static const bool fold_t_env = !(merv_tuning_env("MERV_LN_FOLD_TEMPORAL") && merv_tuning_env("MERV_LN_FOLD_TEMPORAL")[0] == '0');  // A/B hook
     const bool fold_tqkv = fold_qkv && d.temporal_frames > 0 && ntok >= 256 && fold_t_env;
 
     // ---- transformer blocks ----
@@ -737,6 +737,7 @@ extern "C" int merv_preprocess_languagebind(const void* frames_u8, int32_t T, in
 }
 
 // Tuning / test hook: force a GEMM tile configuration (0 = automatic choice).
+extern "C" int merv_tuning_hooks(void) { return MERV_HOOKS ? 1 : 0; }
 extern "C" void merv_debug_set_gemm_variant(int32_t v) { set_gemm_variant(v); }
 extern "C" void merv_debug_set_attn_rescale_thr(float thr) { set_attn_rescale_thr(thr); }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace merv {
 
@@ -32,6 +33,18 @@ MERV_DEVICE uint32_t pack2bf(float lo, float hi) {
 }
 MERV_DEVICE float bflo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
 MERV_DEVICE float bfhi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// Tuning hooks. The product library reads NO environment variable and keeps no process-global switch (no hidden global
+// state): kernel selection is a function of a call's arguments alone. The probe / test build of the same sources (-DMERV_TUNING_HOOKS:
+// `make hooks` -> merv_amd/lib/libmerv_hip_hooks.so, loaded only under MERV_TUNING_HOOKS=1; tools/probes/build_ab*.sh) reads the MERV_* tuning
+// variables through this function and honours merv_debug_set_gemm_variant / merv_debug_set_attn_rescale_thr (no-ops in the product).
+#ifdef MERV_TUNING_HOOKS
+inline const char* merv_tuning_env(const char* name) { return getenv(name); }
+constexpr bool MERV_HOOKS = true;
+#else
+inline const char* merv_tuning_env(const char*) { return nullptr; }
+constexpr bool MERV_HOOKS = false;
+#endif
 
 // Activation kinds (ABI values, see include/merv_hip.h).
 enum : int { ACT_NONE = 0, ACT_GELU_ERF = 1, ACT_GELU_TANH = 2, ACT_QUICK_GELU = 3 };

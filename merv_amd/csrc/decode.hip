@@ -1150,10 +1150,10 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     // sweep (tools/probes/gemv_dma_probe.hip, round 5) has one row x 8 chunks ahead of two rows x 4 on every plain shape, lm_head
     // included (38.3 against 41.2 us). The hooks below select per class: MERV_GEMV_CFG (all launches, "<rows><chunks>"), or
     // MERV_GEMV_CFG_NORM / _PAIR / _BIG for the launches with a fused norm / the gate-up pair / more than 16384 rows.
-    static const char* cfg = getenv("MERV_GEMV_CFG");
-    static const char* cfg_norm = getenv("MERV_GEMV_CFG_NORM");
-    static const char* cfg_pair = getenv("MERV_GEMV_CFG_PAIR");
-    static const char* cfg_big = getenv("MERV_GEMV_CFG_BIG");
+    static const char* cfg = merv_tuning_env("MERV_GEMV_CFG");
+    static const char* cfg_norm = merv_tuning_env("MERV_GEMV_CFG_NORM");
+    static const char* cfg_pair = merv_tuning_env("MERV_GEMV_CFG_PAIR");
+    static const char* cfg_big = merv_tuning_env("MERV_GEMV_CFG_BIG");
     const long rows_total = (long)a.N + a.Nb + a.Nc;
     // Defaults (round 5, with the block-level norm; q / k / v 20.3 -> 18.5 us, gate / up 32.3 -> 30.7, step 2.99 -> 2.86 ms): one row x 4 chunks
     // for the launches with a fused norm and for the gate-up pair (1 x 8 there: 20.6 / 42.5 us -- 200 registers), 1 x 8 for the plain
@@ -1170,7 +1170,7 @@ hipError_t launch_decode_gemv(const DecodeGemvArgs& a, hipStream_t s) {
     // plain o 7.8 -> 7.3) and the gate-up pair (30.3 -> 29.4); q / k / v with the fused norm measured 18.3 -> 18.6 and stays on gemv_body,
     // lm_head is a tie. MERV_GEMV_XLDS (probe hook): "0" never, "1" the plain launches only, "2" plain launches of any size, "3" the
     // default, "4" every launch the form fits.
-    static const char* xlds = getenv("MERV_GEMV_XLDS");
+    static const char* xlds = merv_tuning_env("MERV_GEMV_XLDS");
     const char xmode = xlds && xlds[0] ? xlds[0] : '3';
     const bool xplain = !a.W2 && !a.norm_w;
     const bool xsize = rows_total <= 16384 || xmode == '4' || (xmode == '2' && xplain);

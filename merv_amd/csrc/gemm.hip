@@ -917,11 +917,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, MERV_PROBE_A_DMA_AUX);
     };
     // the SADDR form goes through inline asm (hipcc selects the vector-address form for the builtin whatever the pointer is made of):
-    // M0 = the piece's LDS byte address, written and declared clobbered inside the statement. The explicit vmcnt waits of the K-loop
+    // M0 = the piece's LDS byte address, written inside the statement and listed in its clobbers (so hipcc never keeps a value of its own
+    // live in M0 across a piece: movrel / readlane indexing, a builtin LDS-DMA of a later edit). The explicit vmcnt waits of the K-loop
     // are the only ordering these pieces have ever had (the compiler never waits for a DMA it issued through the builtin either);
     // the epilogue starts behind a vmcnt(0).
     auto dma_saddr = [&](const char* sbase, uint32_t voff, int lds_off) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base + lds_off) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base + lds_off) : "memory", "m0");
     };
     const int a_kstep = MERV_PROBE_A_KSTEP;  // (product: the constant ROW_BYTES)
     auto dma_a = [&](int sq, int t, int buf) {
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
         if constexpr (MX) {
             if constexpr (SADDR)  // (no builtin DMA beside the asm ones: hipcc's own M0 writes must not meet M0 writes it cannot see)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"((uint32_t)(lane * 4)), "s"(s_base + t * s_stride),
-                             "s"(lds_base + SC_BASE + buf * 2048 + wave * 256) : "memory");
+                             "s"(lds_base + SC_BASE + buf * 2048 + wave * 256) : "memory", "m0");
             else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s_base + t * s_stride + (size_t)(uint32_t)(lane * 4)),
                                                  (__attribute__((address_space(3))) void*)(smem + SC_BASE + buf * 2048 + wave * 256), 4, 0, 0);
@@ -1359,7 +1360,7 @@ int plan_split(const GemmArgs& a) {
     // less than one round (small batches): one partial round of the eight-phase kernel still beats two rounds of 256x128
     // tiles once it has enough blocks (measured end to end against never doing so: +12 % tokens/s at 1 video per step, +8 % at 2, +1 % at 4; threshold 32 vs 96: +5.8 % at 1)
     if (rounds < 1) {
-        static const long min_tiles = getenv("MERV_SUBROUND_MIN_TILES") ? atol(getenv("MERV_SUBROUND_MIN_TILES")) : SUBROUND_MIN_TILES;  // tuning hook
+        static const long min_tiles = merv_tuning_env("MERV_SUBROUND_MIN_TILES") ? atol(merv_tuning_env("MERV_SUBROUND_MIN_TILES")) : SUBROUND_MIN_TILES;  // tuning hook
         return (full_m * tilesN >= min_tiles) ? a.M : 0;
     }
     long k = rounds * num_cus() / tilesN;
@@ -1391,7 +1392,9 @@ inline bool row_add_ok(const GemmArgs& a) {
 
 }  // namespace
 
-void set_gemm_variant(int v) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
+void set_gemm_variant(int v) {  // (product build: a no-op -- see merv_tuning_env, common.h)
+    if constexpr (MERV_HOOKS) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
+}
 
 // Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc % 8 == 0.
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {

@@ -11,10 +11,11 @@ llama2.py:74-76), or loads a local state dict.
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Optional
 
 import torch
+
+from . import _lib  # (binding only: the library itself is loaded when a HipDecoder is built)
 
 
 def llama2_7b_config() -> Dict:
@@ -402,9 +403,9 @@ class HipDecoder(StaticDecoder):
     # the fused attention launch + the plain o-projection; 4.8 us per layer faster): default; MERV_DECODE_SPLIT_MERGE=0 restores them.
     # (Round 4 also built attention + o-projection and the whole step as ONE launch; both bit-identical and slower, removed in round 5:
     # git 05f38ce / 0dad582, EXPERIMENTS.md section 5.)
-    use_split_merge = os.environ.get("MERV_DECODE_SPLIT_MERGE", "1") != "0"
+    use_split_merge = _lib.tuning("MERV_DECODE_SPLIT_MERGE", "1") != "0"
     # greedy generation with the argmax / token hand-over / position increment inside the captured step; MERV_DECODE_GREEDY_GRAPH=0: host loop
-    use_greedy_graph = os.environ.get("MERV_DECODE_GREEDY_GRAPH", "1") != "0"
+    use_greedy_graph = _lib.tuning("MERV_DECODE_GREEDY_GRAPH", "1") != "0"
 
     def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         # the fused attention launch expects its per-head arrival counters at zero and restores them itself; an aborted launch
@@ -418,12 +419,12 @@ class HipDecoder(StaticDecoder):
     # Prefill with the elementwise parts of every layer on libmerv_hip.so (RMSNorm, rotary + cache fill, silu * up: one launch each
     # instead of ~35 PyTorch kernels per layer; same rounding points as `_layer`), the GEMMs and the causal attention on PyTorch-ROCm.
     # MERV_HIP_PREFILL=0 takes the plain PyTorch expression of StaticDecoder.
-    use_hip_prefill = os.environ.get("MERV_HIP_PREFILL", "1") != "0"
+    use_hip_prefill = _lib.tuning("MERV_HIP_PREFILL", "1") != "0"
     # ... and the causal attention on merv_prefill_attention (head dim 128) instead of PyTorch-ROCm's SDPA; MERV_HIP_PREFILL_ATTN=0: SDPA
-    use_hip_prefill_attn = os.environ.get("MERV_HIP_PREFILL_ATTN", "1") != "0"
+    use_hip_prefill_attn = _lib.tuning("MERV_HIP_PREFILL_ATTN", "1") != "0"
 
     # q / k / v of the prompt as one library GEMM (below); MERV_PREFILL_FUSE_QKV=0 keeps the module's three parameters untouched
-    fuse_qkv = os.environ.get("MERV_PREFILL_FUSE_QKV", "1") != "0"
+    fuse_qkv = _lib.tuning("MERV_PREFILL_FUSE_QKV", "1") != "0"
 
     def _qkv_fused(self, attn):
         """The q / k / v projection weights (and biases) of one attention module as ONE [Nq + Nk + Nv, D] matrix, so the prompt's

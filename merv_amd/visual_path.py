@@ -20,7 +20,6 @@ projected [*, 64 rows per frame, llm] bf16 tokens to the rank that fuses the vid
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -85,7 +84,7 @@ class MervVisualPath:
         # cost rank of every encoder (0 = most FLOPs per video): the stream map below is written in ranks
         order = sorted(range(len(self.specs)), key=lambda i: -self.specs[i].flops_per_video())
         self._rank = {i: r for r, i in enumerate(order)}
-        self._stream_map_env = os.environ.get("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
+        self._stream_map_env = _lib.tuning("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
         self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
         self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
         self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
@@ -201,7 +200,7 @@ class MervVisualPath:
         -- full-chip launches -- and the small encoders' under-filled launches run beside the largest's (16 videos, map 0111: 113.2-113.4 ms
         with ranks 0 1 2 3, 112.6-112.9 with 0 3 2 1 or 0 2 3 1, 113.5-113.6 with 0 1 3 2 / 0 3 1 2). Probe hook MERV_ENCODER_ORDER: ranks."""
         E = len(self.encoders)
-        o = os.environ.get("MERV_ENCODER_ORDER")
+        o = _lib.tuning("MERV_ENCODER_ORDER")
         by_rank = sorted(range(E), key=lambda i: self._rank[i])
         if o and sorted(o) == [str(r) for r in range(E)]:
             return [by_rank[int(c)] for c in o]

@@ -586,14 +586,19 @@ def test_gemv_forms_give_the_same_bits_across_processes(dev):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for mode in ("0", "", "4"):
+    for mode in ("0", "", "4", "product"):
         env = dict(os.environ)
         env.pop("MERV_GEMV_XLDS", None)
-        if mode:
+        env.pop("MERV_HIP_LIB", None)
+        env["MERV_TUNING_HOOKS"] = "1"  # the hooks build reads the variable (the product library reads none)
+        if mode == "product":  # ... and the product library itself, with the variable set in its environment: ignored, same bits again
+            env.pop("MERV_TUNING_HOOKS")
+            env["MERV_GEMV_XLDS"] = "0"
+        elif mode:
             env["MERV_GEMV_XLDS"] = mode
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "gemv_bits.py")], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.strip()]
         assert len(lines) == 15, r.stdout
         outs.append(lines)
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]

@@ -6,7 +6,7 @@ import torch.nn.functional as F
 
 from conftest import rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("hooks_library")]  # forced tile configurations: the hooks build (conftest.py)
 
 
 # variant 0 = automatic choice, incl. the split between the eight-phase kernel (complete rounds) and a smaller-tile

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libmerv_hip.so does not export {n}"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.merv_abi_version() == 3
+    assert lib.merv_abi_version() == 4
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -527,3 +527,76 @@ def test_distributed_path_argument_forms_are_validated():
                dict(replicate_fusion=True, exchange="all_gather")):
         with pytest.raises(ValueError, match="form"):
             DistributedVisualPath(None, [], 2, 0, **kw)
+
+
+def test_bench_starts_its_own_ranks_without_an_outer_launcher():
+    """`python3 bench.py --gpus N` (how the driver starts BENCH) must not end in a usage error at N > 1: with WORLD_SIZE unset it
+    starts the N ranks itself as a child process, before any GPU call. Here (no GPU) both ranks must get as far as bench.py's own
+    "needs a ROCm GPU" exit -- i.e. the launcher ran, each rank imported bench.py with RANK / WORLD_SIZE set -- and the return code
+    is the child's."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert "starting 2 rank(s) as a child process" in p.stderr, p.stderr[-2000:]
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr
+    if not torch.cuda.is_available():
+        assert p.returncode != 0
+        assert p.stderr.count("bench.py needs a ROCm GPU") >= 1, p.stderr[-2000:]
+        assert p.stdout.strip() == ""  # no JSON line without a GPU, and nothing else on stdout either
+    # under an outer launcher (WORLD_SIZE set) nothing is spawned
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env2,
+                        capture_output=True, text=True, timeout=600)
+    assert "starting" not in p2.stderr
+
+
+def test_library_override_is_checked_as_strictly_as_the_in_tree_build(monkeypatch, tmp_path):
+    """MERV_HIP_LIB alone is a path override: a stale build (missing ABI symbols / another ABI version) must not load. Only
+    MERV_HIP_LIB_AB=1 beside it (A/B pairs against a previous round's build) binds what is there and reports the rest."""
+    import subprocess
+    from merv_amd import _lib
+    src = tmp_path / "stale.c"
+    src.write_text("int merv_abi_version(void) { return 2; }\nconst char* merv_last_error(void) { return \"\"; }\n")
+    so = tmp_path / "libstale.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("MERV_HIP_LIB", str(so))
+    monkeypatch.delenv("MERV_HIP_LIB_AB", raising=False)
+    with pytest.raises((AttributeError, RuntimeError)):
+        _lib.load()
+    monkeypatch.setenv("MERV_HIP_LIB_AB", "1")
+    lib = _lib.load()
+    assert lib.merv_abi_version() == 2
+    monkeypatch.setattr(_lib, "_lib", None)
+
+
+def test_product_library_has_no_environment_hooks(hooks_library):
+    """no hidden global state. The product library imports no `getenv` and reports merv_tuning_hooks() == 0; the
+    hooks build of the same sources (tests / probes, MERV_TUNING_HOOKS=1 only) exports the same ABI and reports 1. The Python side reads
+    its tuning variables through _lib.tuning(), which answers with the default unless MERV_TUNING_HOOKS=1."""
+    import os
+    import subprocess
+    from merv_amd import _lib
+    assert hooks_library.merv_tuning_hooks() == 1 and hooks_library.merv_abi_version() == _lib.ABI_VERSION
+    for n in _declared_symbols():
+        assert hasattr(hooks_library, n), n
+    product = C.CDLL(str(_lib.LIB_PATH))
+    assert product.merv_tuning_hooks() == 0
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", str(_lib.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined, [l for l in undefined.splitlines() if "getenv" in l]
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", str(_lib.HOOKS_LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    for src in (ROOT / "merv_amd").glob("*.py"):  # only _lib.py touches the environment for tuning names
+        if src.name in ("_lib.py", "load.py"):
+            continue
+        assert "os.environ" not in src.read_text(), src
+    os.environ["MERV_ENCODER_STREAM_MAP"] = "0000"
+    try:
+        assert _lib.tuning("MERV_ENCODER_STREAM_MAP") == "0000"  # (this test runs with the hooks switch on)
+        os.environ["MERV_TUNING_HOOKS"] = "0"
+        assert _lib.tuning("MERV_ENCODER_STREAM_MAP") is None and _lib.tuning("MERV_DECODE_GREEDY_GRAPH", "1") == "1"
+    finally:
+        os.environ.pop("MERV_ENCODER_STREAM_MAP")
+        os.environ["MERV_TUNING_HOOKS"] = "1"

@@ -140,7 +140,7 @@ def _attn_ref(qkv, nseq, L, heads):
 @pytest.mark.parametrize("vtr", ["1", "0"])
 @pytest.mark.parametrize("nseq,L,heads", [(2, 64, 1), (3, 196, 12), (2, 257, 16), (2, 261, 16), (1, 3137, 12), (1, 1, 2),
                                           (1, 65, 2)])
-def test_attention(dev, vtr, nseq, L, heads):
+def test_attention(dev, hooks_library, vtr, nseq, L, heads):
     from merv_amd import ops
     os.environ["MERV_ATTN_VTR"] = vtr
     try:
@@ -169,7 +169,7 @@ def test_attention_spiked_max(dev):
 
 
 @pytest.mark.parametrize("L", [196, 257, 300, 3137])
-def test_attention_first_tile_reference(dev, L):
+def test_attention_first_tile_reference(dev, hooks_library, L):
     """Extreme first key tiles: queries whose scores against EVERY key are ~ -128 nats, ~ +128 nats, and one whose first tile is
     ~ -128 while a later key is ~ +40 (the running reference has to start from the tile's own maximum and move far); each at the
     shipped threshold, thr = 0 and thr = 64."""
@@ -199,7 +199,7 @@ def test_attention_first_tile_reference(dev, L):
 
 @pytest.mark.parametrize("vtr", ["1", "0"])
 @pytest.mark.parametrize("L", [257, 258, 261, 264, 265])
-def test_attention_extra_rows_split_over_key_tiles(dev, vtr, L):
+def test_attention_extra_rows_split_over_key_tiles(dev, hooks_library, vtr, L):
     """257 / 261-token sequences run 8 full query tiles on a 4 x 2 block; the 1..8 rows past them are multiplied against one
     key tile per wave and merged through LDS (attention.hip, XQ). A whole-tensor norm would hide one wrong row in 257, so
     the extra rows are checked on their own -- with a score spike in an early AND a late key tile for the first extra row, so
@@ -229,7 +229,7 @@ def test_attention_extra_rows_split_over_key_tiles(dev, vtr, L):
 
 @pytest.mark.parametrize("vtr", ["1", "0"])
 @pytest.mark.parametrize("nclips,ntok,heads", [(1, 4, 1), (2, 257, 16), (1, 3, 2), (3, 17, 4)])
-def test_temporal_attention(dev, vtr, nclips, ntok, heads):
+def test_temporal_attention(dev, hooks_library, vtr, nclips, ntok, heads):
     from merv_amd import ops
     os.environ["MERV_ATTN_VTR"] = vtr
     try:
@@ -304,7 +304,7 @@ def test_fusion_and_splice(dev):
 
 
 @pytest.mark.parametrize("L,late_key", [(300, 290), (3137, 3000), (261, 250)])
-def test_attention_deferred_max(dev, L, late_key):
+def test_attention_deferred_max(dev, hooks_library, L, late_key):
     """The online softmax moves a query's reference only when a key tile's maximum exceeds it by more than 2^thr (attention.hip,
     deferred max; rule 26 of the guide: force the branch, sweep the threshold). Three queries of head 0 see late keys whose
     scores jump by (a) less than the threshold -- exponentials > 1 against the kept reference --, (b) just above it, (c) far

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MERV_HIP_LIB_AB=1  # tolerant binding for a previous build (merv_amd/_lib.py)
 # ab_all.sh LIB...: ksweep (fixed cost per tile) + gemm_bench + bench.py per library, interleaved twice -> gpurun_out/ab_all.log
 mkdir -p gpurun_out
 OUT=gpurun_out/ab_all.log

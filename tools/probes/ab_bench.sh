@@ -1,4 +1,5 @@
 #!/bin/bash
+export MERV_HIP_LIB_AB=1  # tolerant binding for a previous build (merv_amd/_lib.py)
 # ab_bench.sh LIB...: bench.py (concurrent step + one-stream GEMM leg) per library, interleaved twice; parity / CPU / e2e legs off
 for rep in 1 2; do for lib in "$@"; do
   MERV_HIP_LIB=$PWD/$lib python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-e2e 2>/dev/null | python3 -c "

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MERV_HIP_LIB_AB=1  # tolerant binding for a previous build (merv_amd/_lib.py)
 # ab_gemm.sh LIB...: per library (interleaved, twice): tools/gemm_bench.py 16 0 (the encoder stack's shapes at 16 videos, tile choice
 # of the library) and bench.py (whole step); -> gpurun_out/ab_gemm.log
 mkdir -p gpurun_out

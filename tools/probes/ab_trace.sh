@@ -1,4 +1,5 @@
 #!/bin/bash
+export MERV_HIP_LIB_AB=1  # tolerant binding for a previous build (merv_amd/_lib.py)
 # ab_trace.sh LIB...: rocprofv3 --kernel-trace --stats of `bench.py --sequential --no-prof` per library -> gpurun_out/ab_trace/<lib>.csv (+ top GEMM rows printed)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/ab_trace
