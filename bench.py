@@ -74,7 +74,10 @@ TOKENS_PER_VIDEO = 1024
 BACKBONE_IDS = ["languagebind-video-noclass", "dinov2-video-all-tokens", "vivit-google-b-all-no-cls-16frames",
                 "siglip-vit-b16-224px-all-no-cls"]  # merv/conf/models.py:106-113
 NUM_FRAMES = [16, 16, 32, 16]  # merv/conf/models.py:118
-TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999  # the stated bf16 tolerance
+# the stated bf16 tolerance, two clauses: rel-L2 <= 2e-2, or -- where the reference's own bf16 stack on the same tensors is itself above
+# 2e-2 (one measured case: ViViT behind its final LayerNorm under injected trained-tower statistics, tests/test_outlier_statistics_gpu.py) -- <= 1.10 x that
+# stack's error and <= 2.5e-2; per-token cosine >= 0.999. This bench's parity leg (seeded Gaussian towers) is held to the first clause.
+TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999
 PMC_TRAFFIC_FILE = "profiles/r05_pmc_gemm_traffic.json"  # falls back to the previous round's file when this one is absent
 PMC_TRAFFIC_FALLBACK = "profiles/r04_pmc_gemm_traffic.json"
 GEMM_CLOCK_FILE = "profiles/r05_gemm_energy_bound.json"  # in-kernel clock per GEMM class (tools/probes/gemm_energy_bound.hip, product mapping)
@@ -209,10 +212,28 @@ def parity_and_cpu_baseline(path, specs, ref, device, threads=None, batch=1):
     worst_rel = max([par["fused"]["rel_l2"]] + [v["tokens"]["rel_l2"] for v in par["encoders"].values()])
     worst_cos = min([par["fused"]["min_cos"]] + [v["tokens"]["min_cos"] for v in par["encoders"].values()])
     par["pass"] = bool(worst_rel <= TOL_REL_L2 and worst_cos >= TOL_MIN_COS)
-    cpu = {"value": round(TOKENS_PER_VIDEO / secs, 2), "unit": "visual-tokens/s", "cores": ncores, "cores_used": ncores,
+    single = {"value": round(TOKENS_PER_VIDEO / secs, 2), "cores": ncores, "s_per_video": round(secs, 2),
+              "what": f"one process, one intra-op pool of {ncores} threads, the encoders one after the other (merv.py:563-566 as written)"}
+    # ... and with the four branches in four worker processes (independent until fusion): the fair baseline on a many-core host, where one
+    # pool stops scaling at ~16 threads. Same oracle, same tensors; the result must be the single-process one (it is its checker's checker).
+    workers = None
+    tpw = min(16, max(1, (os.cpu_count() or 1) // len(specs)))
+    try:
+        from oracle.parity import reference_video_workers
+        wf, ww, wsecs, per = reference_video_workers([p.float().cpu() for p in pix], specs, ref["enc_W"], ref["proj_W"], ref["Fw"], tpw)
+        workers = {"value": round(TOKENS_PER_VIDEO / wsecs, 2), "cores": tpw * len(specs), "s_per_video": round(wsecs, 2),
+                   "per_worker_s": [round(x, 2) for x in per],
+                   "fused_rel_l2_vs_single_process": round(float((wf - res["fused"]).norm() / res["fused"].norm()), 8),
+                   "what": f"{len(specs)} worker processes (one per encoder branch: encoder + projector) x {tpw} threads, fusion in the parent; "
+                           "clock: release of the loaded workers -> fused tokens"}
+    except Exception as e:  # noqa: BLE001  (a reported baseline: never costs the line)
+        workers = {"error": f"{type(e).__name__}: {e}"}
+    best = workers if workers.get("value", 0) > single["value"] else single
+    cpu = {"value": best["value"], "unit": "visual-tokens/s", "cores": best["cores"], "cores_used": best["cores"],
            "host_cores": os.cpu_count(), "kind": "port",
            "sample": (f"1 video through the whole path, fp32 torch CPU oracle on the GPU path's own weights: patch embed, all consumed "
-                      f"blocks ({par['depth']}), projectors and fusion; {secs:.1f} s/video, nothing extrapolated")}
+                      f"blocks ({par['depth']}), projectors and fusion; {best['s_per_video']:.1f} s/video, nothing extrapolated; the faster of the two forms below"),
+           "single_process": single, "worker_processes": workers}
     return par, cpu
 
 
@@ -616,7 +637,15 @@ def main():
         if single and not args.no_e2e and not args.mxfp8:
             e2e = e2e_generate(bbs, extras, device)
     if world > 1:
-        dist.barrier()
+        # rank 0's single-GPU legs above (roofline passes, the CPU oracle) take minutes: the other ranks wait for them on the HOST (a key in the
+        # process group's store, long timeout) instead of inside an RCCL barrier -- no kernel spinning on seven GPUs beside the one being
+        # timed, and no collective timeout to outlast
+        import datetime
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("merv_bench_rank0_legs_done", "1")
+        else:
+            store.wait(["merv_bench_rank0_legs_done"], datetime.timedelta(minutes=60))
 
     if rank == 0:
         print(json.dumps(make_line(multi_gpu, roof, parity, cpu, e2e)), file=real_stdout, flush=True)

@@ -55,6 +55,9 @@ class MERVVisual(nn.Module):
             if side * side != S:
                 raise ValueError(f"`{vb.identifier}`: {S} tokens per frame do not form an H x W grid -- the reference's "
                                  "AveragePooling3DProjector fails on it too (einops 'B F (H W) C', nn_utils.py:322-326)")
+            if "classemb-at-first" in vb.identifier:  # forward() returns T * S + 1 tokens (the class token in front of all patches)
+                raise ValueError(f"`{vb.identifier}`: forward() returns {T * S + 1} tokens, which do not reshape to [B, {T}, {S}, C] -- the "
+                                 "reference's MERV.forward fails on it too (merv.py:576-585)")
             self._selectors.append((vb.forward, T, side))
         self.feature_fusion_type = feature_fusion
         torch.manual_seed(self.video_backbones[0].embed_dim)  # merv.py:87: projector-init consistency

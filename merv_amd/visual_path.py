@@ -190,7 +190,9 @@ class MervVisualPath:
         against 10.3 / 11.5: small launches need the company). Other encoder counts: one stream each."""
         E = len(self.encoders)
         m = self._stream_map_env
-        if not (m and len(m) == E):
+        if m and not (len(m) == E and all(c.isdigit() and int(c) < len(self.streams) for c in m)):
+            raise ValueError(f"MERV_ENCODER_STREAM_MAP={m!r}: expected {E} digits, each below {len(self.streams)} (a side stream per encoder rank)")
+        if not m:
             m = ("0111" if batch >= 12 else "0112" if batch >= 2 else "0123") if E == 4 else "".join(str(i) for i in range(E))
         return [int(m[self._rank[i]]) for i in range(E)]
 

@@ -52,3 +52,57 @@ def reference_video(pixels: Sequence[torch.Tensor], specs: Sequence, enc_W: Sequ
         projected.append(O.projector_forward(tok, cfg.t_out, cfg.hp, out_size, pw.float(), pb.float()))
     fused, w = O.fusion_forward(projected, Fw)
     return {"tokens": tokens, "projected": projected, "fused": fused, "weights": w}, time.perf_counter() - t0
+
+
+
+@torch.no_grad()
+def reference_video_workers(pixels: Sequence[torch.Tensor], specs: Sequence, enc_W: Sequence[Dict],
+                            proj_W: Sequence[Tuple[torch.Tensor, torch.Tensor]], Fw: Dict[str, torch.Tensor], threads_per_worker: int,
+                            out_size: int = 8, timeout: float = 900.0):
+    """The same video as reference_video, with the E encoder branches (independent until fusion, merv.py:563-566) in E worker processes of
+    `threads_per_worker` threads each (oracle/cpu_worker.py) -- the fair CPU baseline on a many-core host, where ONE torch intra-op pool
+    stops scaling at ~16 threads on these shapes. Workers are child processes with fresh interpreters (the caller may hold a GPU context);
+    their inputs travel as files in a temporary directory (/dev/shm when present), and they load them and build their thread pools BEFORE
+    the clock starts. The clock covers release -> every branch's projected tokens written -> read back and fused in this process.
+    Returns (fused, weights, seconds, per-worker compute seconds)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(prefix="merv_cpu_baseline_", dir=base) as tmp:
+        procs = []
+        try:
+            for i, (pix, spec, W, (pw, pb)) in enumerate(zip(pixels, specs, enc_W, proj_W)):
+                torch.save({"pix": pix.float(), "cfg": spec_to_cfg(spec), "W": W, "pw": pw.float(), "pb": pb.float(), "out_size": out_size},
+                           f"{tmp}/in{i}.pt")
+                env = dict(os.environ, OMP_NUM_THREADS=str(threads_per_worker), MKL_NUM_THREADS=str(threads_per_worker))
+                procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", f"{tmp}/in{i}.pt", f"{tmp}/out{i}.pt", str(threads_per_worker)],
+                                              cwd=str(root), env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+            for p in procs:
+                line = p.stdout.readline()
+                if line.strip() != "ready":
+                    raise RuntimeError(f"oracle.cpu_worker did not start: {line!r}")
+            t0 = time.perf_counter()
+            for p in procs:
+                p.stdin.write("go\n")
+                p.stdin.flush()
+            per = []
+            for p in procs:
+                line = p.stdout.readline().split()
+                if len(line) != 2 or line[0] != "done":
+                    raise RuntimeError(f"oracle.cpu_worker failed: {line!r}")
+                per.append(float(line[1]))
+            projected = [torch.load(f"{tmp}/out{i}.pt") for i in range(len(procs))]
+            fused, w = O.fusion_forward(projected, Fw)
+            total = time.perf_counter() - t0
+        finally:
+            for p in procs:
+                try:
+                    p.stdin.close()
+                    p.wait(timeout=20)
+                except Exception:
+                    p.kill()
+    return fused, w, total, per

@@ -600,3 +600,67 @@ def test_product_library_has_no_environment_hooks(hooks_library):
     finally:
         os.environ.pop("MERV_ENCODER_STREAM_MAP")
         os.environ["MERV_TUNING_HOOKS"] = "1"
+
+
+@pytest.mark.parametrize("bridge", ["native", "torch"])
+def test_load_video_decord_branch_with_a_stand_in_reader(monkeypatch, tmp_path, bridge):
+    """merv_amd/video_io.py's .mp4 / .avi branch (datasets.py:125-157: VideoReader(path, ctx=cpu(0)) -> len / get_avg_fps -> the clip's
+    frame ids -> get_batch(ids) -> [T,H,W,C] -> [T,C,H,W]). decord is absent from this image, so a stand-in module with the four calls
+    the branch makes is injected: get_batch returns an NDArray-like object with .asnumpy() ("native") or a torch tensor (what the
+    reference sees after decord.bridge.set_bridge("torch")). The selected frames must be the ones numpy's linspace expression names."""
+    import sys
+    import types
+    from merv_amd.video_io import load_video
+    N, fps = 300, 29.97
+    clip = np.random.default_rng(0).integers(0, 256, (N, 6, 8, 3), dtype=np.uint8)
+    clip[:, 0, 0, 0] = np.arange(N) % 256  # every frame carries its index
+    clip[:, 0, 0, 1] = np.arange(N) // 256
+    calls = {}
+
+    class _ND:
+        def __init__(self, a):
+            self._a = a
+
+        def asnumpy(self):
+            return self._a
+
+    class VideoReader:
+        def __init__(self, path, ctx=None):
+            calls["path"], calls["ctx"] = path, ctx
+
+        def __len__(self):
+            return N
+
+        def get_avg_fps(self):
+            return fps
+
+        def get_batch(self, ids):
+            calls["ids"] = [int(i) for i in ids]
+            a = clip[np.asarray(calls["ids"])]
+            return torch.from_numpy(a) if bridge == "torch" else _ND(a)
+
+    mod = types.ModuleType("decord")
+    mod.VideoReader, mod.cpu = VideoReader, (lambda i=0: ("cpu", i))
+    monkeypatch.setitem(sys.modules, "decord", mod)
+    path = tmp_path / "clip.mp4"
+    path.write_bytes(b"")
+    for kw in (dict(num_frames=32), dict(num_frames=16, clip_start_sec=2.0, clip_end_sec=7.5), dict(num_frames=8, end_frame=120),
+               dict(num_frames=16, clip_start_sec=float("nan"), clip_end_sec=float("nan"))):
+        out = load_video(str(path), **kw)
+        n = kw["num_frames"]
+        start = 0.0 if kw.get("clip_start_sec") is None or np.isnan(kw.get("clip_start_sec", 0.0)) else kw["clip_start_sec"]
+        end = kw.get("clip_end_sec")
+        end = N / fps if end is None or np.isnan(end) else end
+        if kw.get("end_frame") is not None:
+            want = np.linspace(0, min(N - 1, kw["end_frame"]), n, dtype=int)
+        else:
+            want = np.linspace(start * fps, min(N - 1, end * fps - 1), n, dtype=int)  # datasets.py:131-141
+        assert calls["ids"] == want.tolist() and calls["path"] == str(path) and calls["ctx"] == ("cpu", 0)
+        assert out.dtype == torch.uint8 and tuple(out.shape) == (n, 3, 6, 8) and out.is_contiguous()
+        got = out[:, 0, 0, 0].long() + 256 * out[:, 1, 0, 0].long()
+        assert got.tolist() == want.tolist()
+        assert torch.equal(out, torch.from_numpy(clip[want]).permute(0, 3, 1, 2))
+    # without decord: a loud ImportError, never a silent fallback
+    monkeypatch.setitem(sys.modules, "decord", None)
+    with pytest.raises(ImportError, match="decord"):
+        load_video(str(path), num_frames=8)
