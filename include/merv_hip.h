@@ -30,7 +30,8 @@ extern "C" {
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
  *    section 5) are no longer exported; every other entry point unchanged
- * 4 (round 6): merv_tuning_hooks added; the product build reads no environment variable and merv_debug_set_* are no-ops in it */
+ * 4 (round 6): merv_tuning_hooks and merv_debug_gemm_mxfp8_forms added; the product build reads no environment variable and
+ *    merv_debug_set_* are no-ops in it */
 #define MERV_ABI_VERSION 4
 
 /* activation kinds */
@@ -295,6 +296,15 @@ void merv_debug_set_attn_rescale_thr(float thr);
 /* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */
 int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t M, int32_t N, int32_t K, void *q_out,
                            void *scales_out, void *stream);
+/* Test hook: the MXFP8 GEMM with every epilogue term the encoder stacks use in MXFP8 mode under the LayerNorm fold (round 6) -- folded
+ * LayerNorm (row_stats [M][2], ln_colsum [N]), LayerNorm partials out (stats_out [N/64][M][2]), LanguageBind's row-indexed add, an MXFP8
+ * copy of the result beside bf16 C (keep_c = 1) or instead of it (keep_c = 0) -- and no_static_form = 1 keeps the run-time epilogue form,
+ * so that the static (whole-tile) forms can be compared with it bit for bit. Contiguous operands (lda = ldw = K, ldc = ldres = N). */
+int merv_debug_gemm_mxfp8_forms(const void *A8, const void *scale_a, const void *W8, const void *scale_w, void *C, const float *bias,
+                                const float *lscale, const void *res, int32_t M, int32_t N, int32_t K, int32_t act,
+                                const float *row_stats, const float *ln_colsum, float *stats_out, const float *row_add,
+                                int32_t row_add_div, int32_t row_add_mod, void *mx_out_q, void *mx_out_scales, int32_t keep_c,
+                                int32_t no_static_form, void *stream);
 /* test hook: the bf16 GEMM with the LayerNorm-partials output the encoder requests from the GEMMs that write its residual
  * stream: per row, per 64 output columns, {sum, M2 about the 64-column mean} of the bf16-rounded values stored
  * ([N/64][M][2] floats: column tile major), which a one-thread-per-row kernel combines (Chan) into the statistics of a LayerNorm folded into

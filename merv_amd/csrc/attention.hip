@@ -548,7 +548,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnArgs p) {
                 o = fmaf(w, src[lane], o);
                 l = fmaf(w, src[HD + 1] + src[HD + 2], l);
             }
-            p.out[((size_t)seq * L + XQ0 + row) * D + head * HD + lane] = f2bf(o / l);
+            const bf16_t ob = f2bf(o / l);
+            if constexpr (MXQ) {  // MXFP8 output: the row's 64 columns are two 32-column blocks, one per half-wave (lane = column)
+                const float f = bf2f(ob);
+                float amax = fabsf(f);
+#pragma unroll
+                for (int sh = 1; sh < 32; sh <<= 1) amax = fmaxf(amax, __shfl_xor(amax, sh, 64));
+                const int e = mx_shared_exponent(amax);
+                const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+                const int grow = seq * L + XQ0 + row, col = head * HD + lane;
+                p.mx_q[(size_t)grow * D + col] = (uint8_t)(mx_pack4(f, 0.f, 0.f, 0.f, inv) & 0xffu);
+                if ((lane & 31) == 0) p.mx_scales[mx_scale_offset(grow, col >> 5, p.mx_groups)] = (uint8_t)(e + 127);
+            } else {
+                p.out[((size_t)seq * L + XQ0 + row) * D + head * HD + lane] = ob;
+            }
         }
     }
     char* stg = smem + wave * (32 * 128);
@@ -1034,7 +1047,7 @@ hipError_t launch_attention(const AttnArgs& a_in, hipStream_t s) {
     if (force && force[0] == '4') return launch_attn_cfg<4, 2>(a, s);
     if (t32 <= 4) return launch_attn_cfg<4, 1>(a, s);
     // 8 full tiles + 1..8 rows (257 / 261 tokens): 4 x 2 block, the extra rows split over the waves by key tile
-    if (a.L > 256 && a.L <= 256 + XQ_ROWS && !a.mx_q) {
+    if (a.L > 256 && a.L <= 256 + XQ_ROWS) {  // (MXFP8 output too since round 6: the extra rows' merge quantises its row per half-wave)
         if (force && force[0] == 'x') return launch_attn_cfg<4, 2, true>(a, s);  // streamed K / V tiles (A/B of the resident form)
         if (use_vtr()) return launch_attn_cfg<4, 2, true, true>(a, s);           // all K / V rows resident in LDS
         return launch_attn_cfg<4, 2, true>(a, s);

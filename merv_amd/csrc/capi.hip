@@ -69,6 +69,11 @@ struct StreamDeviceGuard {
 struct MxLayer {  // MXFP8 copies of one block's four GEMM weights (elements + block scales)
     const uint8_t *qkv_q, *qkv_s, *proj_q, *proj_s, *fc1_q, *fc1_s, *fc2_q, *fc2_s;
     const uint8_t *tqkv_q, *tqkv_s, *tproj_q, *tproj_s;  // LanguageBind temporal sub-block (null otherwise)
+    // with the LayerNorm fold (mx_folded): qkv_q / fc1_q / tqkv_q above are quantised from the FOLDED weights bf16(W * gamma) and these are the
+    // column sums of their de-quantised rows (the fold's -mean * rstd * colsum term has to cancel what the scaled MFMA summed); block 0 of
+    // LanguageBind keeps a LayerNorm kernel in front of its temporal qkv (its x comes from the embedding), so the unfolded weight is kept too
+    const float *qkv_cs, *fc1_cs, *tqkv_cs;
+    const uint8_t *tqkv_raw_q, *tqkv_raw_s;
 };
 
 struct FoldLayer {  // LN1 folded into qkv, LN2 into fc1 (LanguageBind: the temporal LayerNorm into the temporal qkv): bf16(W * gamma), sum_k of it, W.beta + bias
@@ -81,6 +86,7 @@ struct merv_encoder {
     merv_encoder_weights w;
     std::vector<merv_layer_weights> layers;
     bool mx = false;            // MXFP8 mode enabled (merv_encoder_enable_mxfp8)
+    bool mx_folded = false;     // ... on the LayerNorm-folded weights (the fold was enabled first): no LayerNorm / quantisation pass in front of qkv / fc1
     int mx_mask = 15;           // which block GEMMs use it: bit 0 qkv (+ temporal qkv), 1 out-projection (+ temporal), 2 fc1, 3 fc2
     std::vector<MxLayer> mxl;
     bool fold = false;          // LayerNorm folded into the qkv / fc1 GEMMs (merv_encoder_enable_ln_fold)
@@ -156,6 +162,7 @@ struct Workspace {
     bf16_t *x, *y, *qkv, *h;
     uint8_t *aq, *asc;  // MXFP8 mode: quantised [M, dim] GEMM input (LayerNorm / attention output) and its block scales
     uint8_t *hq, *hsc;  // MXFP8 mode: quantised [M, mlp_dim] MLP hidden activations, written by fc1's epilogue
+    uint8_t *xq, *xsc;  // MXFP8 mode with the LayerNorm fold: the residual stream's MXFP8 copy, written by the epilogue of the GEMM that wrote x
     float* stats;       // folded LayerNorm: {rstd, -mean * rstd} per row
     float* parts;       // folded LayerNorm: per-row {sum, M2} partials per 64 columns, written by the producing GEMM's epilogue
     size_t total;
@@ -176,12 +183,16 @@ Workspace carve(const merv_encoder* e, int nseq, char* base) {
     w.y = take(M * D * 2);
     w.qkv = take(M * 3 * D * 2);
     w.h = take(M * hcols * 2);
-    w.aq = w.asc = w.hq = w.hsc = nullptr;
+    w.aq = w.asc = w.hq = w.hsc = w.xq = w.xsc = nullptr;
     if (e->mx) {
         w.aq = (uint8_t*)take(M * D);
         w.asc = (uint8_t*)take(mx_scale_bytes((int)M, (int)D));
         w.hq = (uint8_t*)take(M * e->d.mlp_dim);
         w.hsc = (uint8_t*)take(mx_scale_bytes((int)M, e->d.mlp_dim));
+        if (e->mx_folded) {
+            w.xq = (uint8_t*)take(M * D);
+            w.xsc = (uint8_t*)take(mx_scale_bytes((int)M, (int)D));
+        }
     }
     w.stats = e->fold ? (float*)take(M * 2 * sizeof(float)) : nullptr;
     w.parts = e->fold ? (float*)take(M * (D / 64) * 2 * sizeof(float)) : nullptr;
@@ -246,6 +257,10 @@ extern "C" size_t merv_encoder_mxfp8_bytes(const merv_encoder* e) {
     const int D = e->d.dim, H = e->d.mlp_dim;
     size_t per_layer = mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D) + mx_weight_bytes(H, D) + mx_weight_bytes(D, H);
     if (e->d.temporal_frames > 0) per_layer += mx_weight_bytes(3 * D, D) + mx_weight_bytes(D, D);
+    if (e->fold) {  // column sums of the quantised folded weights (+ LanguageBind: the unfolded temporal qkv for block 0's LayerNorm kernel)
+        per_layer += align_up((size_t)3 * D * 4, 256) + align_up((size_t)H * 4, 256);
+        if (e->d.temporal_frames > 0) per_layer += align_up((size_t)3 * D * 4, 256) + mx_weight_bytes(3 * D, D);
+    }
     return (size_t)e->d.layers * per_layer;
 }
 
@@ -269,19 +284,39 @@ extern "C" int merv_encoder_enable_mxfp8(merv_encoder* e, void* buf, size_t byte
         MxQuantArgs a{(const bf16_t*)w, qd, sd, N, K, K};
         return launch_mx_quantize(a, s);
     };
+    // With the LayerNorm fold enabled (the default: merv_encoder_enable_ln_fold ran first) the MXFP8 weights of qkv / fc1 / temporal qkv are
+    // quantised from the FOLDED bf16(W * gamma): their GEMMs then read the MXFP8 copy of the raw residual stream that the producing GEMM's
+    // epilogue wrote (GemmArgs::mx_out_keep_c) and normalise in their own epilogue, like the bf16 fold -- no LayerNorm + quantisation kernel
+    // re-reads the stream (round 6; round 5's MX mode ran 163 such passes per step).
+    const bool folded = e->fold;
+    auto colsum = [&](const uint8_t* q, const uint8_t* sc, int N, int K, const float*& cs) -> hipError_t {
+        float* d = (float*)p;
+        p += align_up((size_t)N * 4, 256);
+        cs = d;
+        return launch_mx_colsum(q, sc, d, N, K, s);
+    };
     for (int i = 0; i < e->d.layers; ++i) {
         const merv_layer_weights& L = e->layers[i];
         MxLayer& m = e->mxl[i];
-        MERV_HIP(quant(L.qkv_w, 3 * D, D, m.qkv_q, m.qkv_s));
+        MERV_HIP(quant(folded ? (const void*)e->fl[i].qkv_w : L.qkv_w, 3 * D, D, m.qkv_q, m.qkv_s));
         MERV_HIP(quant(L.proj_w, D, D, m.proj_q, m.proj_s));
-        MERV_HIP(quant(L.fc1_w, H, D, m.fc1_q, m.fc1_s));
+        MERV_HIP(quant(folded ? (const void*)e->fl[i].fc1_w : L.fc1_w, H, D, m.fc1_q, m.fc1_s));
         MERV_HIP(quant(L.fc2_w, D, H, m.fc2_q, m.fc2_s));
+        if (folded) {
+            MERV_HIP(colsum(m.qkv_q, m.qkv_s, 3 * D, D, m.qkv_cs));
+            MERV_HIP(colsum(m.fc1_q, m.fc1_s, H, D, m.fc1_cs));
+        }
         if (e->d.temporal_frames > 0) {
-            MERV_HIP(quant(L.t_qkv_w, 3 * D, D, m.tqkv_q, m.tqkv_s));
+            MERV_HIP(quant(folded ? (const void*)e->fl[i].tqkv_w : L.t_qkv_w, 3 * D, D, m.tqkv_q, m.tqkv_s));
             MERV_HIP(quant(L.t_proj_w, D, D, m.tproj_q, m.tproj_s));
+            if (folded) {
+                MERV_HIP(colsum(m.tqkv_q, m.tqkv_s, 3 * D, D, m.tqkv_cs));
+                MERV_HIP(quant(L.t_qkv_w, 3 * D, D, m.tqkv_raw_q, m.tqkv_raw_s));
+            }
         }
     }
     e->mx = true;
+    e->mx_folded = folded;
     return 0;
 }
 
@@ -386,12 +421,41 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     };
     // does a folded LayerNorm read x right after the GEMM that writes it here? (then that GEMM produces the partials)
     static const bool fused_stats = !(merv_tuning_env("MERV_LN_FUSED_STATS") && merv_tuning_env("MERV_LN_FUSED_STATS")[0] == '0');  // A/B hook
-    const bool fold_qkv = e->fold && !mx_qkv && fused_stats, fold_fc1 = e->fold && !mx_fc1 && fused_stats;
+    // MXFP8 mode on the folded weights (merv_encoder_enable_mxfp8 after merv_encoder_enable_ln_fold): the MX qkv / fc1 are folded like the bf16
+    // ones -- A = the MXFP8 copy of the raw stream (ws.xq, written by the producing GEMM's epilogue beside bf16 x), W = the quantised
+    // bf16(W * gamma), normalisation in the epilogue with the column sums of the DE-QUANTISED weight. Without the fold's weights (mx_folded
+    // false) an MX qkv / fc1 keeps its LayerNorm + quantisation kernel.
+    const bool mxf = e->mx && e->mx_folded;
+    const bool folded_qkv = e->fold && (!mx_qkv || mxf), folded_fc1 = e->fold && (!mx_fc1 || mxf);
+    const bool fold_qkv = folded_qkv && fused_stats, fold_fc1 = folded_fc1 && fused_stats;
     // LanguageBind: the temporal LayerNorm of blocks 1 .. folds into the temporal qkv GEMM as well -- the previous block's fc2 epilogue
     // adds this block's temporal embedding into x (GemmArgs::row_add) and leaves the statistics partials, so no kernel re-reads x.
     // Block 0 keeps the LayerNorm kernel (its x comes from the embedding / pre-LayerNorm).
     static const bool fold_t_env = !(merv_tuning_env("MERV_LN_FOLD_TEMPORAL") && merv_tuning_env("MERV_LN_FOLD_TEMPORAL")[0] == '0');  // A/B hook
     const bool fold_tqkv = fold_qkv && d.temporal_frames > 0 && ntok >= 256 && fold_t_env;
+    // the stream's MXFP8 copy: valid when the GEMM that last wrote x left it (produce_x); else one quantisation pass makes it (block 0)
+    bool xq_valid = false;
+    auto need_xq = [&]() -> hipError_t {
+        if (xq_valid) return hipSuccess;
+        xq_valid = true;
+        MxQuantArgs qa{ws.x, ws.xq, ws.xsc, M, D, D};
+        return launch_mx_quantize(qa, s);
+    };
+    // `o` writes the residual stream; the next reader is a folded LayerNorm (`stats`) whose GEMM runs on MXFP8 operands (`mx_copy`)
+    auto produce_x = [&](GemmArgs& o, bool stats, bool mx_copy) {
+        if (stats) o.stats_out = ws.parts;
+        if (stats && mx_copy) { o.mx_out_q = ws.xq; o.mx_out_scales = ws.xsc; o.mx_out_groups = mx_groups; o.mx_out_keep_c = 1; }
+        parts_valid = stats;
+        xq_valid = stats && mx_copy;
+    };
+    // a LayerNorm-folded consumer of x: statistics, then either the bf16 fold's operands or (MX) the stream's MXFP8 copy
+    auto fold_consumer = [&](GemmArgs& g, bool is_mx, const bf16_t* wf, const float* db, const float* cs, const float* cs_mx) -> hipError_t {
+        if (hipError_t err = ln_stats(); err != hipSuccess) return err;
+        g.bias = db; g.row_stats = ws.stats;
+        if (is_mx) { g.ln_colsum = cs_mx; return need_xq(); }
+        g.A = ws.x; g.W = wf; g.ln_colsum = cs;
+        return hipSuccess;
+    };
 
     // ---- transformer blocks ----
     for (int li = 0; li < d.layers; ++li) {
@@ -399,40 +463,42 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
         if (d.temporal_frames > 0) {
             // x += temporal_embedding[t]; x += out_proj(temporal_attn(LN_t(x)))   (modeling_video.py:133-155)
             GemmArgs q = gemm_args(ws.y, D, L.t_qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.t_qkv_b, ACT_NONE);
-            if (fold_tqkv && li > 0) {  // x already carries temporal_embedding (previous fc2) and its partials are in ws.parts
-                MERV_HIP(ln_stats());
-                q.A = ws.x; q.W = e->fl[li].tqkv_w; q.bias = e->fl[li].tqkv_db;
-                q.row_stats = ws.stats; q.ln_colsum = e->fl[li].tqkv_cs;
+            const bool tfold = fold_tqkv && li > 0;  // x already carries temporal_embedding (previous fc2) and its partials are in ws.parts
+            if (tfold) {
+                MERV_HIP(fold_consumer(q, mx_qkv, e->fl[li].tqkv_w, e->fl[li].tqkv_db, e->fl[li].tqkv_cs, mx_qkv ? e->mxl[li].tqkv_cs : nullptr));
             } else {
                 LayerNormArgs ln{ws.x, ws.y, L.t_ln_w, L.t_ln_b, L.t_emb, M, D, ntok, d.temporal_frames, d.ln_eps};
                 if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
                 MERV_HIP(launch_layernorm(ln, s));
+                parts_valid = xq_valid = false;  // (the kernel added the temporal embedding into x)
             }
-            if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
-            else MERV_HIP(launch_gemm(q, s));
+            if (mx_qkv) {
+                if (tfold) MERV_HIP(mx_gemm(q, ws.xq, ws.xsc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
+                else if (mxf) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_raw_q, e->mxl[li].tqkv_raw_s));  // (tqkv_q holds the folded weight)
+                else MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
+            } else {
+                MERV_HIP(launch_gemm(q, s));
+            }
             TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
             if (mx_proj) { ta.mx_q = ws.aq; ta.mx_scales = ws.asc; ta.mx_groups = mx_groups; }
             MERV_HIP(launch_temporal_attention(ta, s));
             GemmArgs o = gemm_args(ws.y, D, L.t_proj_w, D, ws.x, D, M, D, L.t_proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D;
-            if (fold_qkv) o.stats_out = ws.parts;  // LN1 reads this x next
+            produce_x(o, fold_qkv, mx_qkv);  // LN1 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
             else MERV_HIP(launch_gemm(o, s));
-            parts_valid = fold_qkv;
         }
         {
-            const bool folded = e->fold && !mx_qkv;  // no LayerNorm pass; the normalisation is algebra in the GEMM epilogue
+            const bool folded = folded_qkv;  // no LayerNorm pass; the normalisation is algebra in the GEMM epilogue
             GemmArgs q = gemm_args(ws.y, D, L.qkv_w, D, ws.qkv, 3 * D, M, 3 * D, L.qkv_b, ACT_NONE);
             if (folded) {
-                MERV_HIP(ln_stats());
-                q.A = ws.x; q.W = e->fl[li].qkv_w; q.bias = e->fl[li].qkv_db;
-                q.row_stats = ws.stats; q.ln_colsum = e->fl[li].qkv_cs;
+                MERV_HIP(fold_consumer(q, mx_qkv, e->fl[li].qkv_w, e->fl[li].qkv_db, e->fl[li].qkv_cs, mx_qkv ? e->mxl[li].qkv_cs : nullptr));
             } else {
                 LayerNormArgs ln{ws.x, ws.y, L.ln1_w, L.ln1_b, nullptr, M, D, 1, 1, d.ln_eps};
                 if (mx_qkv) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
                 MERV_HIP(launch_layernorm(ln, s));
             }
-            if (mx_qkv) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
+            if (mx_qkv) MERV_HIP(mx_gemm(q, folded ? ws.xq : ws.aq, folded ? ws.xsc : ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
             else MERV_HIP(launch_gemm(q, s));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
             at.q_prescaled = folded;  // the folded qkv weight carries scale * log2(e) in its q rows
@@ -440,38 +506,34 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             MERV_HIP(launch_attention(at, s));
             GemmArgs o = gemm_args(ws.y, D, L.proj_w, D, ws.x, D, M, D, L.proj_b, ACT_NONE);
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
-            if (fold_fc1) o.stats_out = ws.parts;  // LN2 reads this x next
+            produce_x(o, fold_fc1, mx_fc1);  // LN2 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
             else MERV_HIP(launch_gemm(o, s));
-            parts_valid = fold_fc1;
         }
         {
-            const bool folded = e->fold && !mx_fc1;
+            const bool folded = folded_fc1;
             GemmArgs f1 = gemm_args(ws.y, D, L.fc1_w, D, ws.h, d.mlp_dim, M, d.mlp_dim, L.fc1_b, d.act);
             if (folded) {
-                MERV_HIP(ln_stats());
-                f1.A = ws.x; f1.W = e->fl[li].fc1_w; f1.bias = e->fl[li].fc1_db;
-                f1.row_stats = ws.stats; f1.ln_colsum = e->fl[li].fc1_cs;
+                MERV_HIP(fold_consumer(f1, mx_fc1, e->fl[li].fc1_w, e->fl[li].fc1_db, e->fl[li].fc1_cs, mx_fc1 ? e->mxl[li].fc1_cs : nullptr));
             } else {
                 LayerNormArgs ln{ws.x, ws.y, L.ln2_w, L.ln2_b, nullptr, M, D, 1, 1, d.ln_eps};
                 if (mx_fc1) { ln.mx_q = ws.aq; ln.mx_scales = ws.asc; ln.mx_groups = mx_groups; }
                 MERV_HIP(launch_layernorm(ln, s));
             }
             if (mx_fc2) { f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups; }  // fc2's input, whichever kernel runs fc1
-            if (mx_fc1) MERV_HIP(mx_gemm(f1, ws.aq, ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
+            if (mx_fc1) MERV_HIP(mx_gemm(f1, folded ? ws.xq : ws.aq, folded ? ws.xsc : ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
             else MERV_HIP(launch_gemm(f1, s));
             GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
             // the next reader of x is the following block's LN1 -- unless that block starts with the temporal sub-block
             // (its LayerNorm kernel first adds the temporal embedding into x) or this was the last block
             const bool next_ln1 = fold_qkv && li + 1 < d.layers && (d.temporal_frames == 0 || fold_tqkv);
-            if (next_ln1) f2.stats_out = ws.parts;
+            produce_x(f2, next_ln1, mx_qkv);
             if (next_ln1 && d.temporal_frames > 0) {  // x += the NEXT block's temporal_embedding[frame of the row], here
                 f2.row_add = e->layers[li + 1].t_emb; f2.row_add_div = ntok; f2.row_add_mod = d.temporal_frames;
             }
             if (mx_fc2) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
             else MERV_HIP(launch_gemm(f2, s));
-            parts_valid = next_ln1;
         }
     }
 
@@ -677,6 +739,29 @@ extern "C" int merv_debug_gemm_mx_out(const void* A, const void* W, void* C_unus
 
 // test hook: merv_gemm_bf16's epilogue set plus the LayerNorm-partials output the encoder requests from the GEMMs that write
 // its residual stream (GemmArgs::stats_out): lets the parity tests check the epilogue statistics through the C ABI.
+extern "C" int merv_debug_gemm_mxfp8_forms(const void* A8, const void* scale_a, const void* W8, const void* scale_w, void* C, const float* bias,
+                                          const float* lscale, const void* res, int32_t M, int32_t N, int32_t K, int32_t act,
+                                          const float* row_stats, const float* ln_colsum, float* stats_out, const float* row_add,
+                                          int32_t row_add_div, int32_t row_add_mod, void* mx_out_q, void* mx_out_scales, int32_t keep_c,
+                                          int32_t no_static_form, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(A8 && scale_a && W8 && scale_w && C, "merv_debug_gemm_mxfp8_forms: null argument");
+    MERV_CHECK(M > 0 && N > 0 && N % 256 == 0 && K >= 512 && K % 256 == 0, "merv_debug_gemm_mxfp8_forms: need N % 256 == 0, K % 256 == 0, K >= 512");
+    MERV_CHECK(act >= ACT_NONE && act <= ACT_QUICK_GELU, "merv_debug_gemm_mxfp8_forms: unknown activation");
+    MERV_CHECK(!mx_out_q || mx_out_scales, "merv_debug_gemm_mxfp8_forms: an MXFP8 output needs its scale array");
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = (const bf16_t*)A8; g.W = (const bf16_t*)W8; g.C = (bf16_t*)C; g.bias = bias; g.lscale = lscale; g.res = (const bf16_t*)res;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N; g.ldres = N; g.act = act;
+    g.mx_scale_a = scale_a; g.mx_scale_w = scale_w; g.mx_groups_a = (M + 63) / 64; g.mx_groups_w = N / 64;
+    g.row_stats = row_stats; g.ln_colsum = ln_colsum; g.stats_out = stats_out;
+    g.row_add = row_add; g.row_add_div = row_add_div; g.row_add_mod = row_add_mod;
+    g.mx_out_q = (uint8_t*)mx_out_q; g.mx_out_scales = (uint8_t*)mx_out_scales; g.mx_out_groups = (M + 63) / 64; g.mx_out_keep_c = keep_c;
+    g.no_static_form = no_static_form;
+    MERV_HIP(launch_gemm_mx(g, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int merv_debug_gemm_stats(const void* A, const void* W, void* C, const float* bias, const float* lscale, const void* res,
                                      int32_t M, int32_t N, int32_t K, int32_t act, float* stats_out, void* stream_) {
     MERV_STREAM_DEVICE(stream_);

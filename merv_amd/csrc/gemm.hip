@@ -242,13 +242,17 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
     // MSPLIT >= 4 (A/B builds, -DMERV_GEMM_EPI_PARTS=4): residual rows are requested ONE PART AHEAD -- part p + 1's loads are issued
     // before part p is staged and stored, into the other half of a two-part register buffer (the registers of one part of twice the rows)
     // WHOLE: 0 = any tile, every optional term decided at run time. Otherwise a bit set, all of it compile time: bit 0 = every row of the tile is
-    // valid and the output is bf16 (no MXFP8), bit 1 = a residual, bit 2 = LayerNorm partials out, bit 3 = the row-indexed add. Behind a run-time
+    // valid, bit 1 = a residual, bit 2 = LayerNorm partials out, bit 3 = the row-indexed add, bits 4 / 5 = an MXFP8 output beside / instead of bf16 C. Behind a run-time
     // test a memory instruction is "maybe not issued" to hipcc's waitcnt pass, and the tests in every row's body kept it from batching the part's
     // read-backs: the static forms are straight-line code (stage, read back two ahead, store).
     constexpr bool ALLVALID = WHOLE != 0;
     constexpr bool PIPE = MSPLIT >= 4 || ((WHOLE & 2) && MSPLIT >= 2);
     const bool has_res = WHOLE ? (WHOLE & 2) != 0 : p.res != nullptr;
-    const bool mx_out = WHOLE ? false : p.mx_out_q != nullptr;  // (the launcher gives MXFP8-output launches the WHOLE = 0 form)
+    // MXFP8 output: bit 4 = the result goes out as bf16 C AND as MXFP8 (the residual stream + its quantised copy for the next, LayerNorm-folded MX GEMM),
+    // bit 5 = as MXFP8 only (fc1 -> fc2). Static forms with these bits exist for the MX kernels only (launch_8phase2); bf16 launches with an MXFP8
+    // output take the run-time form.
+    const bool mx_out = WHOLE ? (WHOLE & 48) != 0 : p.mx_out_q != nullptr;
+    const bool store_c = WHOLE ? (WHOLE & 32) == 0 : (p.mx_out_q == nullptr || p.mx_out_keep_c != 0);
     const bool has_stats = WHOLE ? (WHOLE & 4) != 0 : p.stats_out != nullptr;
     const bool has_row_add = WHOLE ? (WHOLE & 8) != 0 : p.row_add != nullptr;
     u32x4 res_ahead[PIPE ? 2 : 1][EP_IT];
@@ -379,7 +383,8 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                     *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
                     if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
                 }
-            } else if (valid[it] && MERV_PROBE_STORE_COND(p)) {
+            }
+            if (store_c && valid[it] && MERV_PROBE_STORE_COND(p)) {  // (uniform)
                 // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
                 // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
                 MERV_PROBE_STORE16(t, (u32x4*)(p.C + (size_t)c_off[it]));
@@ -430,6 +435,7 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
     const bool has_res = WHOLE ? (WHOLE & 2) != 0 : p.res != nullptr;
     const bool has_stats = WHOLE ? (WHOLE & 4) != 0 : p.stats_out != nullptr;
     const bool mx_out = WHOLE ? false : p.mx_out_q != nullptr;
+    const bool store_c = WHOLE ? true : (p.mx_out_q == nullptr || p.mx_out_keep_c != 0);
     // opaque copy of the lane id: keeps the epilogue's index arithmetic below the K-loop (see gemm_epilogue)
     int elane = lane;
     asm volatile("" : "+v"(elane));
@@ -549,7 +555,8 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                         if (fq == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)(ex + 127);
                     }
                 }
-            } else if (valid[j] && MERV_PROBE_STORE_COND(p)) {
+            }
+            if (store_c && valid[j] && MERV_PROBE_STORE_COND(p)) {  // (uniform)
                 // streaming stores (no L2 allocation: see gemm_epilogue)
                 MERV_PROBE_STORE16(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
                 MERV_PROBE_STORE16(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
@@ -849,7 +856,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     constexpr int BKE = ROW_BYTES / ES;           // elements of K per K-tile
     constexpr int SC_BASE = 2 * BUF_BYTES;        // MX: 2 x 2 KB of block scales above the two operand buffers
     constexpr bool DIRECT = gemm_direct_epilogue<ACT> && !MX;  // MX: the W block scales are laid out by (unpermuted) row fragment
-    static_assert(!MX || EPI == EPI_GENERIC, "MXFP8 launches take the generic epilogue");
+    static_assert(MX || (WHOLE & 48) == 0, "static forms with an MXFP8 output exist for the MX kernels only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     MERV_GSTAMP_REAL(0);
     MERV_GSTAMP_HWID(14);
@@ -949,7 +956,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     if constexpr (MX) {
         const bool is_w = wave >= 4;
         const int gtot = is_w ? p.mx_groups_w : p.mx_groups_a;
-        int gidx = (is_w ? n0 : m0) / 64 + (wave & 3);
+        int gidx = (is_w ? n0 : m0) / 64 + (wave & 3) + (is_w ? 0 : p.mx_group0_a);
         gidx = gidx < gtot ? gidx : gtot - 1;
         s_base = (const char*)(is_w ? p.mx_scale_w : p.mx_scale_a) + (size_t)gidx * 256;
         s_stride = (size_t)gtot * 256;
@@ -1033,8 +1040,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_8phase_kernel(GemmArgs p) {
     // this instruction never accumulates in place (destination != source C: it doubled the accumulator registers and
     // copied them every iteration). The scale byte is an instruction field: byte b of the dword = op_sel bit (b & 1),
     // op_sel_hi bit (b >> 1), first slot for the first operand. Hazards the compiler cannot see inside asm are avoided
-    // by construction: operands come straight from ds_read (waited for by lgkmcnt(0)), each accumulator is touched once
-    // per K-tile, and the epilogue is separated from the last MFMA by barriers plus explicit s_nops.
+    // by construction: operands come straight from ds_read -- waited for by the counted lgkmcnt waits hipcc puts in front of the asm statements
+    // that name them as inputs (there is no blanket lgkmcnt(0) behind a phase's barrier since round 5, MERV_GEMM_PH_LGKM); the block scales
+    // sc_a / sc_w are read in phase 1 BEFORE that phase's W fragments and LDS returns in order, so a wait that releases a W fragment has
+    // released the scales as well (an edit that moves read_scales behind the fragment reads would break this) --, each accumulator is
+    // touched once per K-tile, and the epilogue is separated from the last MFMA by barriers plus explicit s_nops.
 #define MERV_MX_ASM(ACC, WOP, AOP, SW, SA, OL0, OL1, OH0, OH1)                                                          \
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[" #OL0 "," #OL1 ",0] op_sel_hi:[" #OH0 \
                  "," #OH1 ",0]"                                                                                          \
@@ -1224,6 +1234,28 @@ hipError_t launch_8phase2(const GemmArgs& a, hipStream_t s) {
             }
         }
     }
+    // MXFP8 launches (round 6): the same static forms where the encoder stacks produce them in MX mode with the LayerNorm fold -- qkv / temporal qkv
+    // (folded, bf16 out), fc1 (folded, activation, MXFP8 out only), out-projections / fc2 (residual + LayerNorm partials, optionally the MXFP8 copy of the
+    // stream and LanguageBind's row-indexed add). Anything else takes the run-time form OF THE SAME EPILOGUE MODE (the modes round differently --
+    // EPI_PLAIN starts the accumulators at the bias, EPI_FOLD nests its two fmas --, and a launch's rows must not depend on which form computed them:
+    // the ragged rows behind the whole tiles are a second launch of the run-time form; mx_static_form below names the static set).
+    if constexpr (MERV_GEMM_ALLVALID && WHOLE == 0 && !REMAP && MX && (EPI == EPI_PLAIN || EPI == EPI_LS || EPI == EPI_FOLD)) {
+        if (a.M % 256 == 0 && !a.no_static_form) {
+            const int f = 1 | (a.res ? 2 : 0) | (a.stats_out ? 4 : 0) | (a.row_add ? 8 : 0) | (a.mx_out_q ? (a.mx_out_keep_c ? 16 : 32) : 0);
+            if constexpr (EPI == EPI_FOLD && ACT == ACT_NONE) {
+                if (f == 1) return launch_8phase2<REMAP, ACT, EPI, MX, 1>(a, s);
+            } else if constexpr (EPI == EPI_FOLD) {
+                if (f == 33) return launch_8phase2<REMAP, ACT, EPI, MX, 33>(a, s);
+            } else if constexpr (ACT == ACT_NONE) {
+                if (f == 7) return launch_8phase2<REMAP, ACT, EPI, MX, 7>(a, s);
+                if (f == 23) return launch_8phase2<REMAP, ACT, EPI, MX, 23>(a, s);
+                if constexpr (EPI == EPI_PLAIN) {
+                    if (f == 15) return launch_8phase2<REMAP, ACT, EPI, MX, 15>(a, s);
+                    if (f == 31) return launch_8phase2<REMAP, ACT, EPI, MX, 31>(a, s);
+                }
+            }
+        }
+    }
     constexpr int LDS = 2 * (256 + 256) * ROW_BYTES + (MX ? 4096 : 0);  // 128 KB (+ 4 KB of MX block scales)
     auto kern = gemm_bf16_8phase_kernel<REMAP, ACT, MX, EPI, WHOLE>;
     static bool attr_set[MAX_DEVICES] = {};  // per instantiation, per device
@@ -1258,8 +1290,28 @@ hipError_t launch_8phase(const GemmArgs& a, hipStream_t s) {
         default: return launch_8phase2<false, ACT, EPI_GENERIC>(a, s);
     }
 }
+// which MXFP8 launches have a static epilogue form (launch_8phase2): a whole number of 256-row tiles and one of the encoder stacks' combinations
+inline bool mx_static_form(const GemmArgs& a) {
+    if (!MERV_GEMM_ALLVALID || a.M % 256 != 0 || a.no_static_form) return false;
+    const int epi = epi_mode(a);
+    const int f = 1 | (a.res ? 2 : 0) | (a.stats_out ? 4 : 0) | (a.row_add ? 8 : 0) | (a.mx_out_q ? (a.mx_out_keep_c ? 16 : 32) : 0);
+    if (epi == EPI_FOLD) return a.act == ACT_NONE ? f == 1 : f == 33;
+    if (a.act != ACT_NONE) return false;
+    if (epi == EPI_PLAIN) return f == 7 || f == 23 || f == 15 || f == 31;
+    if (epi == EPI_LS) return f == 7 || f == 23;
+    return false;
+}
 template <int ACT>
-hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) { return launch_8phase2<false, ACT, EPI_GENERIC, true>(a, s); }
+hipError_t launch_8phase_mx(const GemmArgs& a, hipStream_t s) {  // the epilogue mode by the launch's arguments, as launch_8phase
+    switch (epi_mode(a)) {
+        case EPI_PLAIN: return launch_8phase2<false, ACT, EPI_PLAIN, true>(a, s);
+        case EPI_FOLD: return launch_8phase2<false, ACT, EPI_FOLD, true>(a, s);
+        case EPI_LS:
+            if constexpr (ACT == ACT_NONE) return launch_8phase2<false, ACT, EPI_LS, true>(a, s);
+            return launch_8phase2<false, ACT, EPI_GENERIC, true>(a, s);
+        default: return launch_8phase2<false, ACT, EPI_GENERIC, true>(a, s);
+    }
+}
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool STAGGER, bool REMAP, int ACT, int EPI, int WHOLE = 0>
 hipError_t launch_cfg2(const GemmArgs& a, hipStream_t s) {
@@ -1349,7 +1401,11 @@ int choose_variant(const GemmArgs& a) {
     return a.M > 1024 ? 4 : 1;
 }
 
-constexpr long SUBROUND_MIN_TILES = 32;
+// Round 6, re-swept on the round's kernels (tools/sessions/gpu_r6_s3.sh, ms per step at one video, two passes): 32: 9.97 / 9.97 -- 40: 9.79 / 9.81 -- 72: 9.71 / 9.60 --
+// 96: 9.57 / 9.63; two and four videos unchanged (their narrow launches have >= 128 tiles). A sub-round launch lasts as long as ONE block's K-loop, which
+// is MFMA-bound on its CU (0.93 us per K-tile with the chip part empty): the 68-tile launches of LanguageBind / DINOv2 (proj, fc2: 24 / 66 us alone) finish
+// in 17 / 45 us as 136 staggered 256 x 128 blocks, the 39-tile ones of ViViT / SigLIP (20 / 52 us) in 12 / 29 us as 150 blocks of 128 x 128.
+constexpr long SUBROUND_MIN_TILES = 96;
 // rows (a multiple of 256 -- or all M rows -- possibly 0) the eight-phase kernel should take from the top of the problem
 int plan_split(const GemmArgs& a) {
     if (g_gemm_variant != 0) return 0;
@@ -1358,7 +1414,8 @@ int plan_split(const GemmArgs& a) {
     const long tilesN = a.N / 256, full_m = a.M / 256;
     const long rounds = full_m * tilesN / num_cus();
     // less than one round (small batches): one partial round of the eight-phase kernel still beats two rounds of 256x128
-    // tiles once it has enough blocks (measured end to end against never doing so: +12 % tokens/s at 1 video per step, +8 % at 2, +1 % at 4; threshold 32 vs 96: +5.8 % at 1)
+    // tiles once it has enough blocks (measured end to end against never doing so: +12 % tokens/s at 1 video per step, +8 % at 2, +1 % at 4; the threshold
+    // itself: see SUBROUND_MIN_TILES)
     if (rounds < 1) {
         static const long min_tiles = merv_tuning_env("MERV_SUBROUND_MIN_TILES") ? atol(merv_tuning_env("MERV_SUBROUND_MIN_TILES")) : SUBROUND_MIN_TILES;  // tuning hook
         return (full_m * tilesN >= min_tiles) ? a.M : 0;
@@ -1387,7 +1444,7 @@ hipError_t launch_act(const GemmArgs& a, hipStream_t s) {
 inline bool row_add_ok(const GemmArgs& a) {
     if (!a.row_add) return true;
     if (a.act != ACT_NONE || gemm_direct_epilogue<ACT_NONE>) return false;
-    return a.row_add_div >= 256 && a.row_add_mod > 0 && a.out_group <= 0 && !a.mx_out_q;
+    return a.row_add_div >= 256 && a.row_add_mod > 0 && a.out_group <= 0;  // (an MXFP8 output quantises the values AFTER the add: fine)
 }
 
 }  // namespace
@@ -1453,19 +1510,44 @@ hipError_t launch_gemm_mx(const GemmArgs& a_in, hipStream_t s) {
     GemmArgs a = a_in;
     if (a.stats_out && a.stats_ld <= 0) a.stats_ld = a.M;  // as launch_gemm: rows of the partials array [N / 64][stats_ld][2]
     if (!row_add_ok(a)) return hipErrorInvalidValue;
-    if (!a.mx_scale_a || !a.mx_scale_w || a.mx_groups_a < (a.M + 63) / 64 || a.mx_groups_w < a.N / 64) return hipErrorInvalidValue;
+    if (!a.mx_scale_a || !a.mx_scale_w || a.mx_groups_a < a.mx_group0_a + (a.M + 63) / 64 || a.mx_group0_a < 0 || a.mx_groups_w < a.N / 64) return hipErrorInvalidValue;
     if (a.K % 256 != 0 || a.K < 512 || a.N % 256 != 0 || a.out_group > 0 || a.res_row_mod > 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw) % 16 != 0 || a.ldc % 8 != 0 || (a.res && a.ldres % 8 != 0)) return hipErrorInvalidValue;
     if ((double)a.M * a.ldc >= 4294967296.0 || (a.res && (double)a.M * a.ldres >= 4294967296.0)) return hipErrorInvalidValue;
     ProfScope ps(PROF_GEMM, s, 2.0 * a.M * a.N * a.K,
                  (double)a.M * a.K + (double)a.N * a.K + 2.0 * (double)a.M * a.N * (a.res ? 2 : 1));
-    switch (a.act) {
-        case ACT_NONE: return launch_8phase_mx<ACT_NONE>(a, s);
-        case ACT_GELU_ERF: return launch_8phase_mx<ACT_GELU_ERF>(a, s);
-        case ACT_GELU_TANH: return launch_8phase_mx<ACT_GELU_TANH>(a, s);
-        case ACT_QUICK_GELU: return launch_8phase_mx<ACT_QUICK_GELU>(a, s);
-        default: return hipErrorInvalidValue;
+    auto dispatch = [&](const GemmArgs& g) -> hipError_t {
+        ProfScope pk(g.act == ACT_NONE ? PROF_K_GEMM8_PLAIN : PROF_K_GEMM8_ACT, s, 2.0 * g.M * g.N * g.K,
+                     (double)g.M * g.K + (double)g.N * g.K + 2.0 * (double)g.M * g.N * (g.res ? 2 : 1));
+        switch (g.act) {
+            case ACT_NONE: return launch_8phase_mx<ACT_NONE>(g, s);
+            case ACT_GELU_ERF: return launch_8phase_mx<ACT_GELU_ERF>(g, s);
+            case ACT_GELU_TANH: return launch_8phase_mx<ACT_GELU_TANH>(g, s);
+            case ACT_QUICK_GELU: return launch_8phase_mx<ACT_QUICK_GELU>(g, s);
+            default: return hipErrorInvalidValue;
+        }
+    };
+    // A ragged last tile (ViViT: 16 videos x 3137 rows = 196 tiles + 16 rows) would put the WHOLE launch on the run-time epilogue form: the whole
+    // tiles go first in their static form, the remaining rows follow as a second launch of the generic one (independent rows, same stream).
+    const int rows1 = a.M / 256 * 256;
+    GemmArgs top = a;
+    top.M = rows1;
+    if (rows1 == 0 || rows1 == a.M || !mx_static_form(top)) return dispatch(a);
+    if (hipError_t e = dispatch(top); e != hipSuccess) return e;
+    GemmArgs rest = a;
+    rest.M = a.M - rows1;
+    rest.A = (const bf16_t*)((const uint8_t*)a.A + (size_t)rows1 * a.lda);  // (e4m3 bytes: lda is in elements = bytes)
+    rest.mx_group0_a = a.mx_group0_a + rows1 / 64;
+    rest.C = a.C + (size_t)rows1 * a.ldc;
+    if (a.res) rest.res = a.res + (size_t)rows1 * a.ldres;
+    if (a.row_stats) rest.row_stats = a.row_stats + 2 * (size_t)rows1;
+    rest.row_add_row0 = a.row_add_row0 + rows1;
+    if (a.stats_out) rest.stats_out = a.stats_out + 2 * (size_t)rows1;
+    if (a.mx_out_q) {
+        rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;
+        rest.mx_out_scales = a.mx_out_scales + (size_t)(rows1 / 64) * 256;
     }
+    return dispatch(rest);
 }
 
 }  // namespace merv

@@ -49,6 +49,9 @@ struct GemmArgs {
     uint8_t* mx_out_q;
     uint8_t* mx_out_scales;
     int mx_out_groups;
+    int mx_out_keep_c;        // with mx_out_q: 1 = bf16 C is written AS WELL (the residual stream and its MXFP8 copy for the next, LayerNorm-folded MX GEMM)
+    int no_static_form;       // test hook (merv_debug_gemm_mxfp8_forms): 1 = launch_gemm_mx keeps the run-time epilogue form whatever the shape
+    int mx_group0_a;          // MXFP8 launches: 64-row group of mx_scale_a this launch's row 0 belongs to (launch_gemm_mx's second launch starts at rows1)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s);
@@ -65,6 +68,9 @@ struct MxQuantArgs {
 };
 hipError_t launch_mx_quantize(const MxQuantArgs& a, hipStream_t s);
 size_t mx_scale_bytes(int rows, int K);
+// colsum[n] = sum_k of the DE-QUANTISED row n of an MXFP8 matrix (q [N, K] + scales in mx_quantize's layout): the LayerNorm fold's
+// column-sum term for a quantised folded weight (the correction -mean * rstd * colsum must cancel what the scaled MFMA summed)
+hipError_t launch_mx_colsum(const uint8_t* q, const uint8_t* scales, float* colsum, int N, int K, hipStream_t s);
 void set_gemm_variant(int v);  // low byte: 0 auto, 1: 128x128 2-deep ring, 3: 256x128, 4: 256x128 staggered, 6: 128x128 4-deep ring,
                                // 7: 256x256 eight-phase (2 and 5 were the retired two-stage 256x256 forms);
                                // second byte: tile-order group size override (tuning / tests)

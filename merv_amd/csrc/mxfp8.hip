@@ -40,7 +40,34 @@ __global__ __launch_bounds__(256) void mx_quantize_kernel(MxQuantArgs p) {
     }
 }
 
+// one wave per row: lane l takes the 32-element blocks l, l + 64, ...
+__global__ __launch_bounds__(256) void mx_colsum_kernel(const uint8_t* q, const uint8_t* scales, float* colsum, int N, int K) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const int groups = (N + 63) >> 6;
+    float acc = 0.f;
+    for (int kb = lane; kb < (K >> 5); kb += 64) {
+        const float sc = __uint_as_float((uint32_t)scales[mx_scale_offset(row, kb, groups)] << 23);  // 2^(byte - 127); byte 0 = 2^-127 (a zero block)
+        const uint32_t* src = (const uint32_t*)(q + (size_t)row * K + kb * 32);
+        float b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int v = (int)src[w];
+            b += (__builtin_amdgcn_cvt_f32_fp8(v, 0) + __builtin_amdgcn_cvt_f32_fp8(v, 1)) + (__builtin_amdgcn_cvt_f32_fp8(v, 2) + __builtin_amdgcn_cvt_f32_fp8(v, 3));
+        }
+        acc = fmaf(b, sc, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) colsum[row] = acc;
+}
+
 }  // namespace
+
+hipError_t launch_mx_colsum(const uint8_t* q, const uint8_t* scales, float* colsum, int N, int K, hipStream_t s) {
+    if (N <= 0 || K <= 0 || K % 128 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mx_colsum_kernel, dim3((N + 3) / 4), dim3(256), 0, s, q, scales, colsum, N, K);
+    return hipGetLastError();
+}
 
 size_t mx_scale_bytes(int rows, int K) { return (size_t)(K / 128) * ((rows + 63) / 64) * 256; }
 

@@ -177,12 +177,32 @@ def mx_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> to
     return F.linear(mx_quantize_dequantize(x.to(torch.bfloat16).float()), mx_quantize_dequantize(w.to(torch.bfloat16).float()), b)
 
 
-def _mhsa(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, heads: int, linear=F.linear) -> torch.Tensor:
+def mx_folded_ln_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float,
+                        scale_rows: int = 0, row_scale: float = 1.0) -> torch.Tensor:
+    """linear(LayerNorm(x)) as the MXFP8 mode computes it under the LayerNorm fold (merv_amd/csrc/capi.hip, round 6): the RAW stream x
+    (bf16) and the folded weight W' = bf16(W * gamma) are what is quantised; the normalisation is algebra behind the product --
+    y = rstd * (dq(x) . dq(W')^T) - rstd * mean * colsum(dq(W')) + (W . beta + b), statistics of the bf16 stream. `scale_rows` /
+    `row_scale`: the first rows of W' (the q rows of qkv) carry a factor before rounding, as the folded weight does (the attention's
+    scale * log2 e); it is divided out of those outputs again here, so the result is the plain linear's."""
+    xb = x.to(torch.bfloat16).float()
+    mean = xb.mean(-1, keepdim=True)
+    var = ((xb - mean) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    rs = torch.ones(w.shape[0])
+    rs[:scale_rows] = row_scale
+    wb = w.to(torch.bfloat16).float()
+    wf = mx_quantize_dequantize((wb * gamma[None] * rs[:, None]).to(torch.bfloat16).float())
+    db = (wb @ beta + (b if b is not None else 0.0)) * rs
+    y = rstd * (mx_quantize_dequantize(xb) @ wf.t()) - rstd * mean * wf.sum(-1) + db
+    return y / rs
+
+
+def _mhsa(x: torch.Tensor, qkv_w, qkv_b, proj_w, proj_b, heads: int, linear=F.linear, qkv_linear=None) -> torch.Tensor:
     """softmax(q k^T / sqrt(d)) v with fused qkv weights; x [N, L, D].
     timm Attention.forward; HF CLIPAttention (q*scale, softmax, no mask; modeling_video.py:98,168); HF VivitSelfAttention."""
     N, L, D = x.shape
     hd = D // heads
-    qkv = linear(x, qkv_w, qkv_b).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    qkv = (qkv_linear or linear)(x, qkv_w, qkv_b).reshape(N, L, 3, heads, hd).permute(2, 0, 3, 1, 4)  # (qkv_linear: the input projection alone in another form)
     q, k, v = qkv[0], qkv[1], qkv[2]
     att = (q @ k.transpose(-1, -2)) * (hd**-0.5)
     att = att.softmax(dim=-1)
@@ -221,9 +241,10 @@ def encoder_embed(pix: torch.Tensor, cfg: EncoderCfg, W: Dict[str, torch.Tensor]
     return emb
 
 
-def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor], mx: bool = False) -> torch.Tensor:
+def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor], mx=False, first: bool = False) -> torch.Tensor:
     """(mx=True: every GEMM of the block -- temporal qkv / out-projection, qkv, attention out-projection, fc1, fc2 --
-    through mx_linear: the MXFP8 mode's emulation.) One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
+    through mx_linear: the MXFP8 mode's emulation. mx="folded": the same with qkv / fc1 (and, past the first block, LanguageBind's temporal qkv)
+    in the LayerNorm-folded form the HIP path takes by default, mx_folded_ln_linear.) One pre-LN block. timm Block (x + ls1(attn(norm1 x)); x + ls2(mlp(norm2 x))); HF VivitLayer; LanguageBind
     CLIPEncoderLayer with its temporal sub-block first (modeling_video.py:133-179)."""
     D = cfg.dim
     lin = mx_linear if mx else F.linear
@@ -237,22 +258,33 @@ def encoder_block(x: torch.Tensor, cfg: EncoderCfg, Lw: Dict[str, torch.Tensor],
         x = h.reshape(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
         residual = x  # :144
         h = x.reshape(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
-        h = F.layer_norm(h, (D,), Lw["t_ln_w"], Lw["t_ln_b"], cfg.ln_eps)  # :147
-        h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads, lin)
+        if mx == "folded" and not first:  # (the first block's temporal LayerNorm stays a kernel on the HIP path: its x comes from the embedding)
+            t_in = lambda hh, w_, b_: mx_folded_ln_linear(hh, Lw["t_ln_w"], Lw["t_ln_b"], w_, b_, cfg.ln_eps)
+            h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads, lin, t_in)
+        else:
+            h = F.layer_norm(h, (D,), Lw["t_ln_w"], Lw["t_ln_b"], cfg.ln_eps)  # :147
+            h = _mhsa(h, Lw["t_qkv_w"], Lw["t_qkv_b"], Lw["t_proj_w"], Lw["t_proj_b"], cfg.heads, lin)
         x = residual + h.reshape(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)  # :155
-    h = F.layer_norm(x, (D,), Lw["ln1_w"], Lw["ln1_b"], cfg.ln_eps)
-    h = _mhsa(h, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads, lin)
+    if mx == "folded":
+        q_in = lambda hh, w_, b_: mx_folded_ln_linear(hh, Lw["ln1_w"], Lw["ln1_b"], w_, b_, cfg.ln_eps, D, (D // cfg.heads) ** -0.5 * 1.4426950408889634)
+        h = _mhsa(x, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads, lin, q_in)
+    else:
+        h = F.layer_norm(x, (D,), Lw["ln1_w"], Lw["ln1_b"], cfg.ln_eps)
+        h = _mhsa(h, Lw["qkv_w"], Lw["qkv_b"], Lw["proj_w"], Lw["proj_b"], cfg.heads, lin)
     if cfg.layerscale:
         h = h * Lw["ls1"]
     x = x + h
-    h = F.layer_norm(x, (D,), Lw["ln2_w"], Lw["ln2_b"], cfg.ln_eps)
-    h = lin(act_fn(cfg.act, lin(h, Lw["fc1_w"], Lw["fc1_b"])), Lw["fc2_w"], Lw["fc2_b"])
+    if mx == "folded":
+        h = lin(act_fn(cfg.act, mx_folded_ln_linear(x, Lw["ln2_w"], Lw["ln2_b"], Lw["fc1_w"], Lw["fc1_b"], cfg.ln_eps)), Lw["fc2_w"], Lw["fc2_b"])
+    else:
+        h = F.layer_norm(x, (D,), Lw["ln2_w"], Lw["ln2_b"], cfg.ln_eps)
+        h = lin(act_fn(cfg.act, lin(h, Lw["fc1_w"], Lw["fc1_b"])), Lw["fc2_w"], Lw["fc2_b"])
     if cfg.layerscale:
         h = h * Lw["ls2"]
     return x + h
 
 
-def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = False) -> torch.Tensor:
+def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx=False) -> torch.Tensor:
     """VideoBackbone.forward -> [B, num_patches, D]:
     languagebind/__init__.py:79-103 (hidden_states[-2], 'noclass'), dinov2_video.py:132-154 (n={L-2}, prefix
     stripped, no final norm), vivit.py:100-118 (last layer + final LayerNorm, drop cls, (B,16,14,14,C)),
@@ -263,13 +295,13 @@ def encoder_forward(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = Fals
     return x.reshape(B, -1, cfg.dim)
 
 
-def encoder_hidden(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx: bool = False) -> torch.Tensor:
+def encoder_hidden(pix: torch.Tensor, cfg: EncoderCfg, W: Dict, mx=False) -> torch.Tensor:
     """Every token of every sequence after the last block run (and the final LayerNorm where the family applies one):
     [B * sequences, prefix + patches, D] -- hidden_states[-2] of the LanguageBind tower, timm's intermediate layer
     (patch and prefix tokens), VivitModel.last_hidden_state."""
     x = encoder_embed(pix, cfg, W)
     for li in range(cfg.layers):
-        x = encoder_block(x, cfg, W["layers"][li], mx)
+        x = encoder_block(x, cfg, W["layers"][li], mx, first=li == 0)
     if cfg.final_ln:
         x = F.layer_norm(x, (cfg.dim,), W["final_ln_w"], W["final_ln_b"], cfg.ln_eps)
     return x

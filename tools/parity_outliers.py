@@ -85,7 +85,9 @@ def err(a, ref, bulk):
 
 
 @torch.no_grad()
-def run(dev, encoders=("languagebind", "dinov2"), scenarios=("outlier_channels", "row_offset", "both"), batch=16, layers=None, threads=16):
+def run(dev, encoders=("languagebind", "dinov2"), scenarios=("outlier_channels", "row_offset", "both"), batch=16, layers=None, threads=16, mxfp8=False):
+    """mxfp8=True adds the MXFP8 mode (BASELINE.json configs[4], opt-in) under the same statistics: with the LayerNorm fold (round 6: the RAW stream
+    and W * gamma are what is quantised) and with LayerNorm + quantisation kernels in front of qkv / fc1 (LayerNorm(x) and W are)."""
     from merv_amd.backbones import random_weights, weights_to
     from merv_amd.encoder import HipEncoder, merv_full_specs
     from oracle import merv_oracle as O
@@ -114,6 +116,12 @@ def run(dev, encoders=("languagebind", "dinov2"), scenarios=("outlier_channels",
                 res[name] = tok_b
                 res[name + "_alone_bit_equal"] = bool(torch.equal(tok_b, tok_1))
                 del enc
+            if mxfp8:
+                for name, fold in (("hip_mxfp8_ln_folded", True), ("hip_mxfp8_ln_separate", False)):
+                    enc = HipEncoder(spec, W, dev, ln_fold=fold).enable_mxfp8()
+                    res[name] = enc.forward(pix)[-1:].clone()
+                    torch.cuda.synchronize()
+                    del enc
             res["torch_rocm_bf16"] = encoder_bf16(one, spec, to_ref_stack(W, dev))
             ref = O.encoder_forward(one.float().cpu(), spec_to_cfg(spec), weights_to(W, "cpu"))
             r = ref.reshape(-1, spec.dim)
@@ -124,7 +132,7 @@ def run(dev, encoders=("languagebind", "dinov2"), scenarios=("outlier_channels",
                                      "always_on_channel_median_abs_over_bulk_spread": round(float(r[:, chans[:2]].abs().median()) / spread, 1) if SCENARIOS[sc]["always"] else None,
                                      "row_mean_over_bulk_spread": round(float((r[:, bulk].mean(1).abs() / r[:, bulk].std(1)).median()), 2)},
                    "note": None if not spec.final_ln else "this tower ends in its final LayerNorm (small gains on the outlier channels): the output stream is normalised"}
-            for k in ("hip_ln_folded", "hip_ln_separate", "torch_rocm_bf16"):
+            for k in ("hip_ln_folded", "hip_ln_separate", "torch_rocm_bf16") + (("hip_mxfp8_ln_folded", "hip_mxfp8_ln_separate") if mxfp8 else ()):
                 ent[k + "_vs_oracle"] = err(res[k], ref, bulk)
             ent["hip_batch_last_video_bit_equal_to_video_alone"] = {k: res[k + "_alone_bit_equal"] for k in ("hip_ln_folded", "hip_ln_separate")}
             ent["hip_folded_vs_hip_separate"] = err(res["hip_ln_folded"], res["hip_ln_separate"], bulk)
@@ -142,8 +150,11 @@ def main():
                    "all channels / bulk channels only",
            "columns": ["hip_ln_folded (product default)", "hip_ln_separate (bench.py --no-ln-fold)", "torch_rocm_bf16 (the reference's stack: library GEMM, SDPA, layer_norm)"],
            "encoders": {}}
-    res["encoders"].update(run(dev, encoders=("languagebind", "dinov2"), scenarios=tuple(SCENARIOS)))
-    res["encoders"].update(run(dev, encoders=("vivit", "siglip"), scenarios=("both",)))
+    mx = "--mxfp8" in sys.argv
+    if mx:
+        res["columns"] += ["hip_mxfp8_ln_folded (bench.py --mxfp8: the raw stream and W * gamma quantised)", "hip_mxfp8_ln_separate (LayerNorm(x) and W quantised)"]
+    res["encoders"].update(run(dev, encoders=("languagebind", "dinov2"), scenarios=tuple(SCENARIOS), mxfp8=mx))
+    res["encoders"].update(run(dev, encoders=("vivit", "siglip"), scenarios=("both",), mxfp8=mx))
     worst = lambda col, key: max(s[col + "_vs_oracle"][key] for e in res["encoders"].values() for s in e.values())
     res["summary"] = {k: {"worst_rel_l2": worst(k, "rel_l2"), "worst_rel_l2_bulk": worst(k, "rel_l2_bulk")} for k in ("hip_ln_folded", "hip_ln_separate", "torch_rocm_bf16")}
     res["summary"]["hip_folded_not_above_torch_rocm_bf16_anywhere"] = all(
