@@ -30,7 +30,7 @@ extern "C" {
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
  *    section 5) are no longer exported; every other entry point unchanged
- * 4 (round 6): merv_tuning_hooks and merv_debug_gemm_mxfp8_forms added; the product build reads no environment variable and
+ * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms and merv_decode_sample_advance added; the product build reads no environment variable and
  *    merv_debug_set_* are no-ops in it */
 #define MERV_ABI_VERSION 4
 
@@ -412,6 +412,18 @@ int merv_decode_oproj_merge(const void *Wo, const void *res, void *y, const floa
  * wins), out_tokens[*pos - pos0] <- the token (out_tokens may be NULL), *pos += 1 -- so that a replayed step leaves the next step's
  * token and position on the device and the host loop launches nothing else per token. */
 int merv_decode_greedy_advance(const float *logits, int32_t V, int64_t *tok, int64_t *pos, int64_t *out_tokens, int64_t pos0, void *stream);
+/* The same hand-over with the token DRAWN from softmax(logits / temperature) -- `do_sample=True, temperature=T` of the reference's
+ * generate() kwargs (scripts/quick_start.py:24-32 -> merv.py:818-825 -> HF GenerationMixin's sampling step: logits / T, softmax,
+ * torch.multinomial) -- as argmax_i(logits_i / T + Gumbel_i): the Gumbel-max trick draws from exactly that categorical distribution
+ * in one pass. The Gumbel variates come from Philox4x32-10 keyed by `seed` with counter (i / 4, *pos), so a captured step replays with
+ * fresh numbers at every position and (seed, position) is reproducible. `params` is a 32-byte block in DEVICE memory, 8-byte aligned,
+ * read by the kernel (nothing of it is baked into a captured graph):
+ *   float inv_temperature; int32 eos_id (< 0: none); uint64 seed; int64 min_new_tokens; int64 first_pos -- eos_id cannot be drawn
+ *   as new token number < min_new_tokens, where the step at position first_pos draws token number 1 (HF
+ *   MinNewTokensLengthLogitsProcessor; number 0 is the token drawn from the prompt's logits).
+ * top-k / top-p / repetition penalty are not implemented here (merv_amd/llm.py keeps them on its host loop). */
+int merv_decode_sample_advance(const float *logits, int32_t V, const void *params, int64_t *tok, int64_t *pos, int64_t *out_tokens,
+                               int64_t pos0, void *stream);
 /* The attention step of timm's AttentionPoolLatent (global_pool='map': what the SigLIP ids without `all-no-cls` return,
  * siglip.py:46-63): one learnt query per head against every token of a frame. kv [nseq*ntok, 2*D] bf16 = [k | v] rows (the kv
  * Linear's output), q [D] fp32 = q Linear of the latent, out [nseq, D] bf16; D = heads * 64, ntok <= 1024. */

@@ -132,6 +132,7 @@ SIGNATURES = {
     "merv_decode_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_oproj_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_decode_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _vp]),
+    "merv_decode_sample_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "merv_tuning_hooks": (C.c_int, []),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_debug_set_attn_rescale_thr": (None, [_f32]),

@@ -1073,6 +1073,16 @@ extern "C" int merv_decode_greedy_advance(const float* logits, int32_t V, int64_
     return 0;
 }
 
+extern "C" int merv_decode_sample_advance(const float* logits, int32_t V, const void* params, int64_t* tok, int64_t* pos, int64_t* out_tokens,
+                                          int64_t pos0, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(logits && params && tok && pos, "merv_decode_sample_advance: null argument");
+    MERV_CHECK(V > 0, "merv_decode_sample_advance: V > 0 required");
+    MERV_CHECK(((uintptr_t)params & 7) == 0, "merv_decode_sample_advance: params must be 8-byte aligned");
+    MERV_HIP(launch_decode_sample_advance(logits, V, params, (long*)tok, (long*)pos, (long*)out_tokens, (long)pos0, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int merv_mean_rows(const void* x, void* out, int32_t groups, int32_t rows, int32_t D, int64_t group_stride_rows,
                               void* stream_) {
     MERV_STREAM_DEVICE(stream_);

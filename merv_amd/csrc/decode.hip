@@ -17,6 +17,7 @@
 //   decode_attn_split_kernel + oproj_merge_kernel   the default pair since round 4: rotary + cache + split attention ending at the
 //                          partials, and the o-projection that merges them under its first weight trip
 //   greedy_advance_kernel  argmax -> next token, token log, position + 1 inside the captured step (greedy search)
+//   sample_advance_kernel  the same hand-over with the token drawn from softmax(logits / T) (Gumbel-max on a Philox stream)
 // (2) The prompt prefill keeps its GEMMs on the library and takes everything between them from here and attention.hip:
 //   rmsnorm_kernel (rows = S), add_rmsnorm_kernel, prefill_rope_cache_kernel, silu_mul_kernel, prefill_attn_kernel
 //
@@ -947,6 +948,79 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(const float* logit
     }
 }
 
+// ---- temperature sampling inside the captured step (round 6): token ~ softmax(logits / T), drawn as argmax_i(logits_i / T + g_i) with ----
+// ---- independent standard Gumbel g_i = -log(-log(u_i)) (the Gumbel-max trick: exactly the categorical distribution torch.multinomial ----
+// ---- draws from, without a normalising pass or a prefix sum). u_i comes from Philox4x32-10 keyed by the call's seed with counter ----
+// ---- (i / 4, position): a counter-based stream, so the captured step replays for every position with fresh numbers and a (seed, ----
+// ---- position) pair always gives the same token. Temperature, seed and the end-of-sequence rule live in DEVICE memory (`params`), ----
+// ---- written by the host before a generation: nothing about them is baked into the graph. Replaces the host loop's ----
+// ---- divide / softmax / multinomial / copy kernels and its one host round trip per token (merv.py:818-825 -> HF GenerationMixin.sample). ----
+struct SampleParams {     // 32 bytes, device memory
+    float inv_temperature;
+    int eos_id;           // < 0: no end-of-sequence token
+    unsigned long seed;
+    long min_new_tokens;  // the end-of-sequence token cannot be drawn as new token number < min_new_tokens ...
+    long first_pos;       // ... where the step at position first_pos draws token number 1 (number 0 was drawn from the prompt's logits)
+};
+MERV_DEVICE void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t lo0 = 0xD2511F53u * c[0], hi0 = __umulhi(0xD2511F53u, c[0]);
+        const uint32_t lo1 = 0xCD9E8D57u * c[2], hi1 = __umulhi(0xCD9E8D57u, c[2]);
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+MERV_DEVICE float gumbel_from_bits(uint32_t x) {
+    const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0, 1): 24 bits, never 0 or 1
+    return -__logf(-__logf(u));
+}
+__global__ __launch_bounds__(1024) void sample_advance_kernel(const float* logits, int V, const SampleParams* prm, long* tok, long* pos,
+                                                              long* out_tokens, long pos0) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const long p = *pos;
+    const float inv_t = prm->inv_temperature;
+    const int eos = (prm->eos_id >= 0 && p - prm->first_pos + 1 < prm->min_new_tokens) ? prm->eos_id : -1;  // barred this step (HF MinNewTokensLength)
+    const uint32_t k0 = (uint32_t)prm->seed, k1 = (uint32_t)(prm->seed >> 32);
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    auto take = [&](float v, int i) {  // ascending i per thread; a NaN logit never wins (torch.multinomial would raise on it)
+        if (i != eos && (v > best || idx == 0x7fffffff)) { best = v; idx = i; }
+    };
+    for (int q = threadIdx.x; 4 * q < V; q += 1024) {
+        uint32_t c[4] = {(uint32_t)q, (uint32_t)p, (uint32_t)((unsigned long)p >> 32), 0x4D455256u};
+        philox4x32_10(c, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * q + j;
+            if (i < V) {
+                const float l = logits[i];
+                take(l == l ? fmaf(l, inv_t, gumbel_from_bits(c[j])) : -INFINITY, i);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = bv[0]; int ix = bi[0];
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > v || (bv[w] == v && bi[w] < ix)) { v = bv[w]; ix = bi[w]; }
+        if (ix == 0x7fffffff) ix = 0;  // (every logit NaN or barred: cannot happen with V > 1)
+        tok[0] = ix;
+        if (out_tokens) out_tokens[p - pos0] = ix;
+        *pos = p + 1;
+    }
+}
+
 // ---- o-projection that merges the attention's split partials on the way in: y = res + W_o . merge(ws) ----
 // One workgroup of 8 waves per 16 output rows (256 workgroups at D = 4096: one per CU, two rows per wave). Every lane first requests
 // the partials of its chunk and then its whole first weight trip (ROWS x 8 chunks of 16 B); the workgroup merges the H x nsplit partials
@@ -1245,6 +1319,12 @@ size_t decode_attention_split_workspace_floats(int H, int nsplit) { return (size
 hipError_t launch_decode_greedy_advance(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s) {
     if (V <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(1024), 0, s, logits, V, tok, pos, out_tokens, pos0);
+    return hipGetLastError();
+}
+hipError_t launch_decode_sample_advance(const float* logits, int V, const void* params, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s) {
+    if (V <= 0 || !params) return hipErrorInvalidValue;
+    static_assert(sizeof(SampleParams) == 32, "merv_decode_sample_advance's params block is 32 bytes (include/merv_hip.h)");
+    hipLaunchKernelGGL(sample_advance_kernel, dim3(1), dim3(1024), 0, s, logits, V, (const SampleParams*)params, tok, pos, out_tokens, pos0);
     return hipGetLastError();
 }
 hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s) {

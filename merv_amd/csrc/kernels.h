@@ -425,5 +425,6 @@ struct DecodeOprojMergeArgs {  // y = res + W . merge(ws): the o-projection behi
 hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s);
 // greedy decoding inside a captured step: tok[0] <- argmax(logits[V]) (first maximum), out_tokens[*pos - pos0] <- it, *pos += 1
 hipError_t launch_decode_greedy_advance(const float* logits, int V, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s);
+hipError_t launch_decode_sample_advance(const float* logits, int V, const void* params, long* tok, long* pos, long* out_tokens, long pos0, hipStream_t s);
 
 }  // namespace merv

@@ -197,6 +197,25 @@ class LlamaBackbone:
                 if hit.numel():
                     ids = ids[:, : int(hit[0]) + 1]
             return ids
+        if (isinstance(dec, HipDecoder) and do_sample and top_k == 0 and top_p >= 1.0 and repetition_penalty == 1.0 and max_new_tokens > 0
+                and dec.use_greedy_graph):
+            # temperature sampling entirely on the device (HipDecoder.sample_run): the first token from the prompt's logits here, with the
+            # caller's generator (which also seeds the device stream: one draw per generation, so a seeded generator reproduces the text)
+            lg = logits / max(temperature, 1e-6)
+            if eos_token_id is not None and min_new_tokens > 0:
+                lg = lg.clone()
+                lg[:, eos_token_id] = float("-inf")
+            first = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator)[:, 0]
+            seed = int(torch.randint(0, 2**62, (1,), generator=generator, device=generator.device if generator is not None else "cpu"))
+            if max_new_tokens == 1 or (eos_token_id is not None and int(first) == eos_token_id):
+                return first[None]
+            rest = dec.sample_run(first, max_new_tokens - 1, inputs_embeds.shape[1], temperature, seed, eos_token_id, min_new_tokens)
+            ids = torch.cat([first, rest])[None]
+            if eos_token_id is not None:
+                hit = (ids[0] == eos_token_id).nonzero()
+                if hit.numel():
+                    ids = ids[:, : int(hit[0]) + 1]
+            return ids
         new_tokens = []
         done = torch.zeros(inputs_embeds.shape[0], dtype=torch.bool, device=inputs_embeds.device)
         for i in range(max_new_tokens):
@@ -469,6 +488,7 @@ class HipDecoder(StaticDecoder):
             if fused is not None:  # a re-fuse: the captured steps read the storage the parameters had before
                 self.graph = None
                 self.greedy_graph = self.greedy_graph_chunk = None
+                self.sample_graph = self.sample_graph_chunk = None
             fused = attn._merv_qkv = (w, b)
         return fused
 
@@ -580,6 +600,58 @@ class HipDecoder(StaticDecoder):
                 done += self.GREEDY_CHUNK
             else:
                 self.greedy_graph.replay()
+                done += 1
+            if eos_token_id is not None and (done % self.GREEDY_CHUNK == 0 or done == steps):  # one host look per chunk
+                if bool((self.out_tokens[start:start + done] == eos_token_id).any()):
+                    break
+        return self.out_tokens[start:start + done].clone()
+
+    # Temperature sampling with nothing but the graph replay per token (round 6): as greedy_run, the captured step ending in
+    # merv_decode_sample_advance -- Gumbel-max on a Philox stream keyed by (seed, position): exactly softmax(logits / T)'s categorical
+    # distribution -- instead of the host loop's divide / softmax / multinomial / copy kernels and one host round trip per token.
+    # Temperature, seed and the end-of-sequence rule are read from device memory (self.sample_params), so one pair of graphs serves
+    # every generation. top-k / top-p / repetition penalty keep the host loop (generate_from_embeds).
+    sample_graph = sample_graph_chunk = None
+
+    @torch.inference_mode()
+    def sample_run(self, token: torch.Tensor, steps: int, start: int, temperature: float, seed: int, eos_token_id: Optional[int] = None,
+                   min_new_tokens: int = 0) -> torch.Tensor:
+        """token [1]: the token at position `start` (= self.pos; new token number 0). Runs up to `steps` decode steps, each DRAWING its
+        successor from softmax(logits / temperature); returns their tokens [n] (int64, device), n <= steps (with an `eos_token_id` the
+        host looks every 8 steps and stops after the chunk that produced it; the token is barred while fewer than `min_new_tokens`
+        have been drawn)."""
+        import struct
+        from ._lib import check, ptr
+        if steps <= 0:
+            return torch.empty(0, dtype=torch.long, device=self.dev)
+        self.tok.copy_(token[:, None])
+        blob = struct.pack("<fiQqq", 1.0 / max(float(temperature), 1e-6), -1 if eos_token_id is None else int(eos_token_id),
+                           int(seed) & (2**64 - 1), int(min_new_tokens), int(start))
+        if not hasattr(self, "sample_params"):
+            self.sample_params = torch.zeros(32, dtype=torch.uint8, device=self.dev)
+        self.sample_params.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        if self.sample_graph is None:
+            self._step()  # warm-up outside the capture; the advance is not run: it would move the position
+            torch.cuda.synchronize(self.dev)
+
+            def capture(nsteps):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(nsteps):
+                        self._step()
+                        check(self.lib.merv_decode_sample_advance(ptr(self.logits32), self.cfg.vocab_size, ptr(self.sample_params), ptr(self.tok),
+                                                                  ptr(self.pos), ptr(self.out_tokens), 0,
+                                                                  torch.cuda.current_stream(self.dev).cuda_stream), "merv_decode_sample_advance")
+                return g
+            self.sample_graph = capture(1)
+            self.sample_graph_chunk = capture(self.GREEDY_CHUNK)
+        done = 0
+        while done < steps:
+            if steps - done >= self.GREEDY_CHUNK:
+                self.sample_graph_chunk.replay()
+                done += self.GREEDY_CHUNK
+            else:
+                self.sample_graph.replay()
                 done += 1
             if eos_token_id is not None and (done % self.GREEDY_CHUNK == 0 or done == steps):  # one host look per chunk
                 if bool((self.out_tokens[start:start + done] == eos_token_id).any()):

@@ -564,6 +564,100 @@ def test_one_decoder_alternating_greedy_and_sampled_generations(dev):
     assert llm.generate_from_embeds(emb, max_new_tokens=1).tolist() == [[first]]
 
 
+def _sample_params(dev, temperature, seed, eos=-1, min_new=0, first_pos=0):
+    import struct
+    blob = struct.pack("<fiQqq", 1.0 / temperature, eos, seed, min_new, first_pos)
+    return torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+
+
+@pytest.mark.parametrize("V,temperature", [(13, 0.4), (320, 1.0), (32064, 0.7)])
+def test_sample_advance_kernel_draws_from_softmax_of_logits_over_temperature(dev, V, temperature):
+    """merv_decode_sample_advance (round 6: `do_sample=True, temperature=T` of scripts/quick_start.py:24-32 inside the captured step): the token
+    is argmax(logits / T + Gumbel noise from a Philox stream keyed by (seed, position)), i.e. a draw from softmax(logits / T). Over 40 000
+    positions the token frequencies must match those probabilities -- and torch.multinomial's own frequencies on the same distribution --
+    within sampling error; (seed, position) is reproducible, another seed is another stream, a NaN logit is never drawn."""
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(V)
+    lg = torch.randn(V, generator=g) * 2.0
+    if V > 1000:  # a realistic head: a few likely tokens, a long tail
+        lg[:8] += 6.0
+    lg[V // 2] = float("nan")
+    probs = torch.softmax(torch.nan_to_num(lg, nan=-float("inf")).double() / temperature, -1)
+    lgd = lg.to(dev)
+    N = 40000
+    tok = torch.zeros(1, 1, dtype=torch.long, device=dev)
+
+    def run(seed, n=N, pos0=100):
+        pos = torch.tensor([pos0], dtype=torch.long, device=dev)
+        out = torch.full((n,), -1, dtype=torch.long, device=dev)
+        prm = _sample_params(dev, temperature, seed)
+        for _ in range(n):
+            check(lib.merv_decode_sample_advance(ptr(lgd), V, ptr(prm), ptr(tok), ptr(pos), ptr(out), pos0, _st(dev)), "sample_advance")
+        torch.cuda.synchronize()
+        assert int(pos) == pos0 + n and int(tok) == int(out[-1])
+        return out.cpu()
+
+    out = run(1234)
+    assert int(out.min()) >= 0 and int(out.max()) < V and not bool((out == V // 2).any())
+    freq = torch.bincount(out, minlength=V).double() / N
+    ref = torch.bincount(torch.multinomial(probs.float(), N, replacement=True, generator=torch.Generator().manual_seed(3)), minlength=V).double() / N
+    sigma = torch.sqrt(probs * (1 - probs) / N)
+    top = probs.topk(min(V, 12)).indices  # where the mass is: per-token frequencies within 5 sigma of the probability
+    assert bool(((freq[top] - probs[top]).abs() <= 5 * sigma[top] + 1e-4).all()), (freq[top], probs[top])
+    # the whole distribution: total variation against the exact probabilities no worse than torch.multinomial's own sample (+ slack)
+    tv, tv_ref = float((freq - probs).abs().sum() / 2), float((ref - probs).abs().sum() / 2)
+    assert tv <= 1.5 * tv_ref + 5e-3, (tv, tv_ref)
+    assert torch.equal(run(1234, 512), out[:512])            # (seed, position) reproduces
+    assert not torch.equal(run(99, 512), out[:512])          # another seed: another stream
+    assert not torch.equal(run(1234, 512, pos0=101)[:-1], out[:511]) or V < 20  # (positions shifted by one: other numbers)
+
+
+def test_sample_advance_bars_the_eos_token_until_min_new_tokens(dev):
+    from merv_amd import _lib
+    from merv_amd._lib import check, ptr
+    lib = _lib.load()
+    V = 64
+    lg = torch.zeros(V)
+    lg[5] = 30.0  # the end-of-sequence token, overwhelmingly likely
+    lgd = lg.to(dev)
+    tok = torch.zeros(1, 1, dtype=torch.long, device=dev)
+    pos = torch.tensor([50], dtype=torch.long, device=dev)
+    out = torch.full((16,), -1, dtype=torch.long, device=dev)
+    prm = _sample_params(dev, 1.0, 7, eos=5, min_new=6, first_pos=50)  # the step at position 50 draws new token number 1
+    for _ in range(16):
+        check(lib.merv_decode_sample_advance(ptr(lgd), V, ptr(prm), ptr(tok), ptr(pos), ptr(out), 50, _st(dev)), "sample_advance")
+    o = out.cpu().tolist()
+    assert all(t != 5 for t in o[:5]) and all(t == 5 for t in o[5:]), o  # numbers 1..5 barred, number 6 onwards free
+
+
+def test_sampled_generation_on_the_device(dev):
+    """generate_from_embeds(do_sample=True, temperature=T) without top-k / top-p / penalty runs on HipDecoder.sample_run: one pair of graphs
+    for every temperature / seed (they are read from device memory), a seeded generator reproduces the tokens, another seed does not, an EOS
+    cuts the result, and greedy / host-loop generations on the same decoder are unaffected."""
+    from merv_amd.llm import HipDecoder, LlamaBackbone
+    llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                             num_key_value_heads=2, max_position_embeddings=2048, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
+    emb = (torch.randn(1, 20, 256, generator=torch.Generator().manual_seed(21)) * 0.5).to(torch.bfloat16).to(dev)
+    gen = lambda seed: torch.Generator(device=dev).manual_seed(seed)
+    greedy = llm.generate_from_embeds(emb, max_new_tokens=33)
+    a = llm.generate_from_embeds(emb, max_new_tokens=33, do_sample=True, temperature=2.0, generator=gen(5))
+    dec = next(iter(llm._decoders.values()))
+    assert isinstance(dec, HipDecoder) and dec.sample_graph is not None and a.shape == (1, 33)
+    b = llm.generate_from_embeds(emb, max_new_tokens=33, do_sample=True, temperature=2.0, generator=gen(5))
+    c = llm.generate_from_embeds(emb, max_new_tokens=33, do_sample=True, temperature=2.0, generator=gen(6))
+    cold = llm.generate_from_embeds(emb, max_new_tokens=33, do_sample=True, temperature=1e-3, generator=gen(6))  # T -> 0: the greedy text
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(cold, greedy), (cold.tolist(), greedy.tolist())
+    assert next(iter(llm._decoders.values())) is dec  # same decoder, same graphs
+    eos_id = int(a[0, 12])
+    cut = llm.generate_from_embeds(emb, max_new_tokens=33, do_sample=True, temperature=2.0, generator=gen(5), eos_token_id=eos_id)
+    k = a[0].tolist().index(eos_id)
+    assert cut.tolist() == [a[0, : k + 1].tolist()]
+    assert torch.equal(llm.generate_from_embeds(emb, max_new_tokens=33), greedy)
+
+
 def test_generate_uses_hip_decoder_when_it_can(dev):
     from merv_amd.llm import HipDecoder, LlamaBackbone, StaticDecoder
     llm = LlamaBackbone(dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
