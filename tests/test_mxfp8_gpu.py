@@ -209,3 +209,26 @@ def test_mx_static_epilogue_forms_give_the_run_time_forms_bits(dev, form, M):
         vals = c0.float().cpu().reshape(M, N // 64, 64)
         sm = vals.sum(-1).t()
         assert torch.allclose(p0[..., 0].cpu(), sm, rtol=1e-4, atol=1e-3)
+
+
+def test_mxfp8_mode_stated_tolerance_at_full_depth(dev):
+    """The MXFP8 mode's stated tolerance (profiles/r06_mxfp8_accuracy.json): relative L2 of the fused visual tokens
+    against the bf16 path on the same random-init weights and inputs, full depth (23 / 23 / 12 / 11 blocks), one video: <= 0.10 with all four
+    block GEMMs on MXFP8 operands (measured 0.079), <= 0.04 with fc2 alone (0.034). Opt-in, never the headline."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+    specs, path = bench.build_path(dev, concurrent=True)
+    pix = bench.synth_pixels(specs, 1, dev, seed=0)
+    ref = path.forward(pix)[0].float().clone()
+    got = {}
+    for gemms in (("fc2",), ("qkv", "proj", "fc1", "fc2")):
+        for e in path.encoders:
+            e.enable_mxfp8(gemms)
+        fused = path.forward(pix)[0].float()
+        assert torch.isfinite(fused).all()
+        got[gemms] = float((fused - ref).norm() / ref.norm())
+    print(got)
+    assert 5e-3 < got[("fc2",)] <= 0.04, got
+    assert got[("fc2",)] < got[("qkv", "proj", "fc1", "fc2")] <= 0.10, got
