@@ -30,7 +30,7 @@ extern "C" {
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
  *    section 5) are no longer exported; every other entry point unchanged
- * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms and merv_decode_sample_advance added; the product build reads no environment variable and
+ * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms, merv_debug_set_rest_fork and merv_decode_sample_advance added; the product build reads no environment variable and
  *    merv_debug_set_* are no-ops in it */
 #define MERV_ABI_VERSION 4
 
@@ -293,6 +293,10 @@ void merv_debug_set_gemm_variant(int32_t variant);
 /* Tuning / test hook (hooks build only): the attention kernels' deferred-max threshold in binary orders of magnitude (a lane's exponentials may sum to
  * 2^thr before its softmax reference moves); 0 = exact running maximum, default 8, values outside [0, 64] restore the default. */
 void merv_debug_set_attn_rescale_thr(float thr);
+/* Experiment hook (hooks build only; a no-op in the product): GEMM launches on `main_stream` put their remaining-rows launch on `aux_stream`
+ * (event-forked before the main launch, event-joined behind it), so that it can start in its own main launch's tail. main_stream = NULL
+ * clears every registration. Round 6, VERDICT r5 item 7: measured, not kept (profiles/r06_remainder_fork.json). */
+void merv_debug_set_rest_fork(void *main_stream, void *aux_stream);
 /* Test hook: plain bf16 GEMM (A [M,K], W [N,K]) whose epilogue writes its result as MXFP8 (q [M,N] + block scales). */
 int merv_debug_gemm_mx_out(const void *A, const void *W, void *C_unused, int32_t M, int32_t N, int32_t K, void *q_out,
                            void *scales_out, void *stream);

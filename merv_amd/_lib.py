@@ -136,6 +136,7 @@ SIGNATURES = {
     "merv_tuning_hooks": (C.c_int, []),
     "merv_debug_set_gemm_variant": (None, [_i32]),
     "merv_debug_set_attn_rescale_thr": (None, [_f32]),
+    "merv_debug_set_rest_fork": (None, [_vp, _vp]),
     "merv_prof_enable": (None, [_i32]),
     "merv_prof_reset": (None, []),
     "merv_prof_read": (C.c_int, [_i32, C.POINTER(_f64), C.POINTER(_i64), C.POINTER(_f64), C.POINTER(_f64)]),

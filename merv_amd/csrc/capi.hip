@@ -413,6 +413,11 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     bool parts_valid = false;
     auto ln_stats = [&]() -> hipError_t {
         if (parts_valid) {
+            // (timing-only ablation, hooks build: the finalize launch dropped -- WRONG results -- bounds what folding it into a GEMM could gain)
+            // (the first 1500 calls run, so that ws.stats holds a previous step's -- for a repeated input: the right -- values and the outputs stay finite)
+            static const bool abl_skip = merv_tuning_env("MERV_ABL_NO_FINALIZE") != nullptr;
+            static int abl_calls = 0;
+            if (abl_skip && ++abl_calls > 1500) return hipSuccess;
             StatsFinalizeArgs fa{ws.parts, ws.stats, M, D / 64, d.ln_eps};
             return launch_stats_finalize(fa, s);
         }
@@ -825,6 +830,7 @@ extern "C" int merv_preprocess_languagebind(const void* frames_u8, int32_t T, in
 extern "C" int merv_tuning_hooks(void) { return MERV_HOOKS ? 1 : 0; }
 extern "C" void merv_debug_set_gemm_variant(int32_t v) { set_gemm_variant(v); }
 extern "C" void merv_debug_set_attn_rescale_thr(float thr) { set_attn_rescale_thr(thr); }
+extern "C" void merv_debug_set_rest_fork(void* main_stream, void* aux_stream) { set_rest_fork((hipStream_t)main_stream, (hipStream_t)aux_stream); }
 
 // ---- single-kernel wrappers ----
 extern "C" int merv_gemm_bf16(const void* A, const void* W, void* C, const float* bias, const float* lscale,

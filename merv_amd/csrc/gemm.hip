@@ -1449,6 +1449,28 @@ inline bool row_add_ok(const GemmArgs& a) {
 
 }  // namespace
 
+// Round-6 experiment (hooks build only): the remaining-rows launch of a GEMM forked onto a sibling stream, so that it can start in
+// its own main launch's tail instead of behind it. set_rest_fork(main, aux) registers the sibling of a stream (the caller picks one that owns an otherwise
+// idle hardware queue); launch_gemm then brackets the second launch with two events. Measured: profiles/r06_remainder_fork.json.
+namespace {
+struct RestFork { hipStream_t main, aux; hipEvent_t fork, join; };
+RestFork g_rest_fork[8];
+int g_rest_forks = 0;
+}
+void set_rest_fork(hipStream_t main, hipStream_t aux) {
+    if constexpr (MERV_HOOKS) {
+        if (!main) { g_rest_forks = 0; return; }
+        for (int i = 0; i < g_rest_forks; ++i)
+            if (g_rest_fork[i].main == main) { g_rest_fork[i].aux = aux; return; }
+        if (g_rest_forks < 8) {
+            RestFork& f = g_rest_fork[g_rest_forks];
+            f.main = main; f.aux = aux;
+            if (hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess)
+                ++g_rest_forks;
+        }
+    }
+}
+
 void set_gemm_variant(int v) {  // (product build: a no-op -- see merv_tuning_env, common.h)
     if constexpr (MERV_HOOKS) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
 }
@@ -1485,6 +1507,13 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (rows1 == 0) return dispatch(a, false);
     GemmArgs top = a;
     top.M = rows1;
+    const RestFork* fork = nullptr;
+    if constexpr (MERV_HOOKS) {
+        if (rows1 != a.M)
+            for (int i = 0; i < g_rest_forks; ++i)
+                if (g_rest_fork[i].main == s && g_rest_fork[i].aux) fork = &g_rest_fork[i];
+        if (fork && hipEventRecord(fork->fork, s) != hipSuccess) fork = nullptr;  // everything the two launches read is behind this point
+    }
     hipError_t e = dispatch(top, true);
     if (e != hipSuccess || rows1 == a.M) return e;
     if constexpr (MERV_PROBE_REST_MODE != 0) return MERV_PROBE_REST_LAUNCH(s, e);
@@ -1499,6 +1528,18 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.mx_out_q) {  // rows1 is a multiple of 256: whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
         rest.mx_out_q = a.mx_out_q + (size_t)rows1 * a.N;
         rest.mx_out_scales = a.mx_out_scales + (size_t)(rows1 / 64) * 256;
+    }
+    if constexpr (MERV_HOOKS) {
+        if (fork) {  // the remaining rows on the sibling stream, joined back before anything that follows on s
+            if (hipError_t fe = hipStreamWaitEvent(fork->aux, fork->fork, 0); fe != hipSuccess) return fe;
+            hipStream_t main = s;
+            s = fork->aux;
+            e = dispatch(rest, false);
+            s = main;
+            if (e != hipSuccess) return e;
+            if (hipError_t fe = hipEventRecord(fork->join, fork->aux); fe != hipSuccess) return fe;
+            return hipStreamWaitEvent(s, fork->join, 0);
+        }
     }
     return dispatch(rest, false);
 }

@@ -53,6 +53,7 @@ struct GemmArgs {
     int no_static_form;       // test hook (merv_debug_gemm_mxfp8_forms): 1 = launch_gemm_mx keeps the run-time epilogue form whatever the shape
     int mx_group0_a;          // MXFP8 launches: 64-row group of mx_scale_a this launch's row 0 belongs to (launch_gemm_mx's second launch starts at rows1)
 };
+void set_rest_fork(hipStream_t main, hipStream_t aux);  // hooks build only (gemm.hip)
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_gemm_mx(const GemmArgs& a, hipStream_t s);
 
