@@ -78,8 +78,8 @@ NUM_FRAMES = [16, 16, 32, 16]  # merv/conf/models.py:118
 # 2e-2 (one measured case: ViViT behind its final LayerNorm under injected trained-tower statistics, tests/test_outlier_statistics_gpu.py) -- <= 1.10 x that
 # stack's error and <= 2.5e-2; per-token cosine >= 0.999. This bench's parity leg (seeded Gaussian towers) is held to the first clause.
 TOL_REL_L2, TOL_MIN_COS = 2e-2, 0.999
-PMC_TRAFFIC_FILE = "profiles/r05_pmc_gemm_traffic.json"  # falls back to the previous round's file when this one is absent
-PMC_TRAFFIC_FALLBACK = "profiles/r04_pmc_gemm_traffic.json"
+PMC_TRAFFIC_FILE = "profiles/r06_pmc_gemm_traffic.json"  # falls back to the previous round's file when this one is absent
+PMC_TRAFFIC_FALLBACK = "profiles/r05_pmc_gemm_traffic.json"
 GEMM_CLOCK_FILE = "profiles/r05_gemm_energy_bound.json"  # in-kernel clock per GEMM class (tools/probes/gemm_energy_bound.hip, product mapping)
 POWER_CAP_FILE = "profiles/r05_mfma_issue_order.json"  # bare MFMA loop on random operands (tools/probes/mfma_hold.hip): what the power cap lets the matrix pipe do
 NOMINAL_CLOCK_GHZ = 2.4  # the engine clock the 2.5 PFLOP/s dense bf16 peak is quoted at (MI355X_MICROARCH.md)

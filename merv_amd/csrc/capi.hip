@@ -413,11 +413,13 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     bool parts_valid = false;
     auto ln_stats = [&]() -> hipError_t {
         if (parts_valid) {
-            // (timing-only ablation, hooks build: the finalize launch dropped -- WRONG results -- bounds what folding it into a GEMM could gain)
-            // (the first 1500 calls run, so that ws.stats holds a previous step's -- for a repeated input: the right -- values and the outputs stay finite)
-            static const bool abl_skip = merv_tuning_env("MERV_ABL_NO_FINALIZE") != nullptr;
-            static int abl_calls = 0;
-            if (abl_skip && ++abl_calls > 1500) return hipSuccess;
+            // (timing-only probe, hooks build: the finalize launch issued TWICE -- same result; the step's slow-down is what the launches cost on
+            // their chains, i.e. the most that folding them into a GEMM could gain. Dropping them instead leaves another layer's statistics: NaNs)
+            static const bool abl_twice = merv_tuning_env("MERV_ABL_DOUBLE_FINALIZE") != nullptr;
+            if (abl_twice) {
+                StatsFinalizeArgs fb{ws.parts, ws.stats, M, D / 64, d.ln_eps};
+                if (hipError_t err = launch_stats_finalize(fb, s); err != hipSuccess) return err;
+            }
             StatsFinalizeArgs fa{ws.parts, ws.stats, M, D / 64, d.ln_eps};
             return launch_stats_finalize(fa, s);
         }
