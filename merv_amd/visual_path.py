@@ -200,12 +200,17 @@ class MervVisualPath:
         """Order in which the branches are enqueued (= executed, for encoders that share a stream): the largest encoder first (it has a
         stream of its own), then the others from the SMALLEST up, so that the chain which ends the step alone is the second-largest encoder's
         -- full-chip launches -- and the small encoders' under-filled launches run beside the largest's (16 videos, map 0111: 113.2-113.4 ms
-        with ranks 0 1 2 3, 112.6-112.9 with 0 3 2 1 or 0 2 3 1, 113.5-113.6 with 0 1 3 2 / 0 3 1 2). Probe hook MERV_ENCODER_ORDER: ranks."""
+        with ranks 0 1 2 3, 112.6-112.9 with 0 3 2 1 or 0 2 3 1, 113.5-113.6 with 0 1 3 2 / 0 3 1 2). With a stream per encoder (one video: what
+        every generate() call is) the order only decides when the host gets round to each chain -- one encoder's launches take the host 0.3-1.2 ms
+        to enqueue --, so the chains start longest first: a single call 10.2 -> 9.35 ms (median of 20, round 6: tools/sessions/gpu_r6_s8.sh; the
+        back-to-back rate, 9.5 ms, does not care). Probe hook MERV_ENCODER_ORDER: ranks."""
         E = len(self.encoders)
         o = _lib.tuning("MERV_ENCODER_ORDER")
         by_rank = sorted(range(E), key=lambda i: self._rank[i])
         if o and sorted(o) == [str(r) for r in range(E)]:
             return [by_rank[int(c)] for c in o]
+        if len(set(self.stream_map(batch))) == E:
+            return by_rank
         return by_rank[:1] + by_rank[:0:-1]
 
     def _run_branches(self, pixels: Sequence[torch.Tensor], project: bool) -> List[torch.Tensor]:
