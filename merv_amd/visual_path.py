@@ -85,6 +85,8 @@ class MervVisualPath:
         order = sorted(range(len(self.specs)), key=lambda i: -self.specs[i].flops_per_video())
         self._rank = {i: r for r, i in enumerate(order)}
         self._stream_map_env = _lib.tuning("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
+        self.threaded_enqueue: Optional[bool] = None  # see _threaded_enqueue
+        self._executor = None
         self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
         self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
         self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
@@ -213,6 +215,21 @@ class MervVisualPath:
             return by_rank
         return by_rank[:1] + by_rank[:0:-1]
 
+    def _threaded_enqueue(self, smap: Sequence[int]) -> bool:
+        """Enqueue the branches from one host thread each? Only when every encoder has a stream of its own (one video per call), never
+        inside a graph capture (a capture belongs to the capturing thread). `threaded_enqueue` (None = that rule) overrides."""
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        if self.threaded_enqueue is not None:
+            return bool(self.threaded_enqueue) and len(set(smap)) == len(smap)
+        return _lib.tuning("MERV_THREADED_ENQUEUE", "0") == "1" and len(set(smap)) == len(smap)
+
+    def _pool(self):
+        if self._executor is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._executor = ThreadPoolExecutor(max_workers=max(1, len(self.encoders) - 1), thread_name_prefix="merv-enqueue")
+        return self._executor
+
     def _run_branches(self, pixels: Sequence[torch.Tensor], project: bool) -> List[torch.Tensor]:
         """The E independent branches (merv.py:563-566), each on its own stream when `concurrent`, event-joined on the
         current stream. project=True: a4-a9 (projected tokens); False: a4-a8 only (encoder tokens [B, T*S, C])."""
@@ -239,12 +256,30 @@ class MervVisualPath:
             start.record(main)
             smap = self.stream_map(pixels[0].shape[0])
             outs = [None] * len(pixels)
-            for i in self.enqueue_order(pixels[0].shape[0]):  # encoders that share a stream run in this order
-                st = self.streams[smap[i]]
-                st.wait_event(start)
-                outs[i] = branch(i, pixels[i], st)
-                dones[i].record(st)
-                main.wait_event(dones[i])
+            order = self.enqueue_order(pixels[0].shape[0])
+            if self._threaded_enqueue(smap):
+                # a stream per encoder (one video per call): every chain is enqueued by its own host thread (an encoder is ONE library call,
+                # which runs without the GIL), so the chains start together instead of 0.3-1.2 ms apart -- the host needs ~2 ms to enqueue a
+                # step's ~700 launches -- and the largest encoder's chain, which ends the step, is never waiting for the host
+                def work(i):
+                    with torch.cuda.device(self.device):
+                        st = self.streams[smap[i]]
+                        st.wait_event(start)
+                        outs[i] = branch(i, pixels[i], st)
+                        dones[i].record(st)
+                futs = [self._pool().submit(work, i) for i in order[1:]]
+                work(order[0])
+                for f in futs:
+                    f.result()
+                for i in order:
+                    main.wait_event(dones[i])
+            else:
+                for i in order:  # encoders that share a stream run in this order
+                    st = self.streams[smap[i]]
+                    st.wait_event(start)
+                    outs[i] = branch(i, pixels[i], st)
+                    dones[i].record(st)
+                    main.wait_event(dones[i])
         else:
             for i, pix in enumerate(pixels):
                 outs.append(branch(i, pix, main))
