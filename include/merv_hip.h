@@ -30,7 +30,8 @@ extern "C" {
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
  *    section 5) are no longer exported; every other entry point unchanged
- * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms, merv_debug_set_rest_fork and merv_decode_sample_advance added; the product build reads no environment variable and
+ * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms, merv_debug_set_rest_fork, merv_decode_sample_advance and
+ *    merv_decode_attention_split_prefetch added; the product build reads no environment variable and
  *    merv_debug_set_* are no-ops in it */
 #define MERV_ABI_VERSION 4
 
@@ -399,6 +400,16 @@ size_t merv_decode_attention_fused_workspace_floats(int32_t H, int32_t nsplit);
 int merv_decode_attention_fused(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t, const int64_t *pos,
                                 void *k_cache, void *v_cache, void *out, float *ws, int32_t H, int32_t Hkv, int32_t hd,
                                 int32_t max_len, int32_t nsplit, float scale, void *stream);
+/* merv_decode_attention_split with a read-only pass over the NEXT launch's weights riding on it (round 6): the split attention is a chain of
+ * dependent round trips over ~17 MB of cache that leaves HBM idle for its ~7 us; `next_w_bytes / next_block_bytes` extra workgroups behind the
+ * H x nsplit attention ones each read `next_block_bytes` of `next_w` -- for the o-projection that follows: W_o, in slices of the 16 rows one
+ * workgroup of merv_decode_oproj_merge reads -- and, workgroups going to the 8 XCDs round-robin (H * nsplit % 8 == 0 required), prefetch workgroup
+ * b lands on the XCD whose L2 workgroup b of the next launch reads through. Same results as merv_decode_attention_split (next_w = NULL: the same
+ * launch). Replaces nothing in the reference: it is how the five launches per layer of HF's LlamaDecoderLayer.forward overlap here. */
+int merv_decode_attention_split_prefetch(const void *q, const void *k, const void *v, const void *cos_t, const void *sin_t,
+                                         const int64_t *pos, void *k_cache, void *v_cache, float *ws, int32_t H, int32_t Hkv, int32_t hd,
+                                         int32_t max_len, int32_t nsplit, float scale, const void *next_w, int64_t next_w_bytes,
+                                         int32_t next_block_bytes, void *stream);
 /* The same two steps with the merge moved into the o-projection (round 4; bit-identical to merv_decode_attention_fused followed by
  * merv_decode_gemv(Wo, NULL, out, x, x, ...)): merv_decode_attention_split ends at the split partials (ws:
  * merv_decode_attention_split_workspace_floats(H, nsplit) floats, 16-byte aligned, records of 132; no counters, no `out`, nothing to

@@ -130,6 +130,7 @@ SIGNATURES = {
     "merv_decode_attention_fused": (C.c_int, [_vp] * 10 + [_i32, _i32, _i32, _i32, _i32, _f32, _vp]),
     "merv_decode_attention_split_workspace_floats": (_sz, [_i32, _i32]),
     "merv_decode_attention_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "merv_decode_attention_split_prefetch": (C.c_int, [_vp] * 9 + [_i32] * 5 + [_f32, _vp, C.c_int64, _i32, _vp]),
     "merv_decode_oproj_merge": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "merv_decode_greedy_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, C.c_int64, _vp]),
     "merv_decode_sample_advance": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, C.c_int64, _vp]),

@@ -1060,6 +1060,24 @@ extern "C" int merv_decode_attention_split(const void* q, const void* k, const v
     return 0;
 }
 
+extern "C" int merv_decode_attention_split_prefetch(const void* q, const void* k, const void* v, const void* cos_t, const void* sin_t,
+                                                    const int64_t* pos, void* k_cache, void* v_cache, float* ws, int32_t H, int32_t Hkv,
+                                                    int32_t hd, int32_t max_len, int32_t nsplit, float scale, const void* next_w,
+                                                    int64_t next_w_bytes, int32_t next_block_bytes, void* stream_) {
+    MERV_STREAM_DEVICE(stream_);
+    MERV_CHECK(q && k && v && cos_t && sin_t && pos && k_cache && v_cache && ws, "merv_decode_attention_split_prefetch: null argument");
+    MERV_CHECK(hd == 128, "merv_decode_attention_split_prefetch: head_dim must be 128");
+    MERV_CHECK(H > 0 && Hkv > 0 && H % Hkv == 0 && nsplit > 0 && nsplit <= 64 && max_len > 0, "merv_decode_attention_split_prefetch: bad geometry");
+    MERV_CHECK(!next_w || (next_block_bytes > 0 && next_block_bytes % 16 == 0 && next_w_bytes > 0 && next_w_bytes / next_block_bytes <= (1 << 20) &&
+                           ((uintptr_t)next_w & 15) == 0 && (H * nsplit) % 8 == 0),
+               "merv_decode_attention_split_prefetch: next_w needs 16-byte alignment, a block size that is a multiple of 16 and H * nsplit % 8 == 0");
+    DecodeAttnFusedArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (bf16_t*)k_cache,
+                          (bf16_t*)v_cache, nullptr, ws, (const long*)pos, H, Hkv, hd, max_len, nsplit, scale,
+                          next_w, next_w ? next_block_bytes : 0, next_w ? (int)(next_w_bytes / next_block_bytes) : 0};
+    MERV_HIP(launch_decode_attention_split(a, (hipStream_t)stream_));
+    return 0;
+}
+
 extern "C" int merv_decode_oproj_merge(const void* Wo, const void* res, void* y, const float* ws, void* attn_out, int32_t N, int32_t H,
                                        int32_t hd, int32_t nsplit, void* stream_) {
     MERV_STREAM_DEVICE(stream_);

@@ -889,6 +889,27 @@ __global__ __launch_bounds__(DA_THREADS) void decode_attn_fused_kernel(DecodeAtt
 }
 __global__ __launch_bounds__(DA_THREADS) void decode_attn_split_kernel(DecodeAttnFusedArgs p) {
     __shared__ AttnLds lds;
+    if (blockIdx.y >= (unsigned)p.nsplit) {
+        // prefetch role (blocks behind the H x nsplit attention blocks; their linear id is a multiple of 8 further on, so prefetch block b shares
+        // its XCD -- its L2 -- with block b of the next launch): read-only pass over that block's slice of the next launch's weights
+        const int b = (blockIdx.y - p.nsplit) * p.H + blockIdx.x;
+        if (b >= p.prefetch_blocks) return;
+        const char* base = (const char*)p.prefetch + (size_t)b * p.prefetch_block_bytes;
+        u32x4 acc = {0u, 0u, 0u, 0u};
+        for (int off = threadIdx.x * 16; off < p.prefetch_block_bytes; off += DA_THREADS * 16 * 8) {
+            u32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int o = off + u * DA_THREADS * 16;
+                v[u] = o < p.prefetch_block_bytes ? *(const u32x4*)(base + o) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u];
+        }
+        // (the loads must not be dead code: a store that never happens -- bf16 weights do not XOR to this pattern in all four words)
+        if (acc[0] == 0x7fc07fc1u && acc[1] == 0x7fc17fc0u && acc[2] == 0x7fc27fc3u && acc[3] == 0x7fc37fc2u) p.ws[0] = 0.f;
+        return;
+    }
     attn_fused_body<true>(p, blockIdx.x, blockIdx.y, lds);
 }
 
@@ -1329,7 +1350,12 @@ hipError_t launch_decode_sample_advance(const float* logits, int V, const void* 
 }
 hipError_t launch_decode_attention_split(const DecodeAttnFusedArgs& a, hipStream_t s) {
     if (a.hd != 128 || a.H <= 0 || a.Hkv <= 0 || a.H % a.Hkv != 0 || a.nsplit <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(decode_attn_split_kernel, dim3(a.H, a.nsplit), dim3(DA_THREADS), 0, s, a);
+    int extra = 0;
+    if (a.prefetch) {
+        if (a.prefetch_blocks <= 0 || a.prefetch_block_bytes <= 0 || a.prefetch_block_bytes % 16 != 0 || (a.H * a.nsplit) % 8 != 0) return hipErrorInvalidValue;
+        extra = (a.prefetch_blocks + a.H - 1) / a.H;
+    }
+    hipLaunchKernelGGL(decode_attn_split_kernel, dim3(a.H, a.nsplit + extra), dim3(DA_THREADS), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_decode_oproj_merge(const DecodeOprojMergeArgs& a, hipStream_t s) {

@@ -409,6 +409,11 @@ struct DecodeAttnFusedArgs {  // rotary(q, k at *pos) + cache[*pos] <- k, v + sp
     const long* pos;
     int H, Hkv, hd, max_len, nsplit;
     float scale;
+    // split launch only (round 6): the NEXT launch's weight matrix (the o-projection's W_o), touched by extra blocks while this launch --
+    // a chain of dependent round trips over 17 MB of cache that leaves HBM idle -- runs: prefetch block b reads bytes [b, b + 1) * prefetch_block_bytes,
+    // the rows o-projection block b will read, and lands on the same XCD as that block (workgroups go to XCDs round-robin), i.e. in ITS L2
+    const void* prefetch;
+    int prefetch_block_bytes, prefetch_blocks;
 };
 hipError_t launch_decode_attention_fused(const DecodeAttnFusedArgs& a, hipStream_t s);
 // the same launch ending at the partials (a.out unused; no counters): ws [H][nsplit][132] = (o[128], m, l, 2 pad) is complete when

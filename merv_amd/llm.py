@@ -423,6 +423,10 @@ class HipDecoder(StaticDecoder):
     # (Round 4 also built attention + o-projection and the whole step as ONE launch; both bit-identical and slower, removed in round 5:
     # git 05f38ce / 0dad582, EXPERIMENTS.md section 5.)
     use_split_merge = _lib.tuning("MERV_DECODE_SPLIT_MERGE", "1") != "0"
+    # round 6, measured and NOT the default: the split attention launch also touching the o-projection's weights, each slice on the XCD whose L2 its
+    # reader uses (merv_decode_attention_split_prefetch). The o-projection gains 2.2 us per layer, the attention launch loses 3.4 (33.5 MB are 5.6 us of
+    # HBM stream: more than the launch's idle time): 2.60-2.64 -> 2.63 ms per token (profiles/r06_decode_mall_bound.json). MERV_DECODE_PREFETCH_WO=1 opts in.
+    prefetch_oproj = _lib.tuning("MERV_DECODE_PREFETCH_WO", "0") == "1"
     # greedy generation with the argmax / token hand-over / position increment inside the captured step; MERV_DECODE_GREEDY_GRAPH=0: host loop
     use_greedy_graph = _lib.tuning("MERV_DECODE_GREEDY_GRAPH", "1") != "0"
 
@@ -681,9 +685,18 @@ class HipDecoder(StaticDecoder):
                       "merv_decode_gemv3_bias")
                 if self.use_split_merge and H <= 256:
                     # rotary + cache + split attention; then x += o_proj(merge of the splits): the merge rides under the weight loads
-                    check(lib.merv_decode_attention_split(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
-                                                          ptr(self.V[li]), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5, st),
-                          "merv_decode_attention_split")
+                    if self.prefetch_oproj and (H * self.NSPLIT) % 8 == 0 and D % 16 == 0:
+                        # ... with W_o touched by extra workgroups meanwhile, each on the XCD whose L2 the o-projection's workgroup of the same
+                        # index reads through (16 rows per workgroup there): the launch leaves HBM idle, the next one then starts from L2
+                        wo = a.o_proj.weight
+                        check(lib.merv_decode_attention_split_prefetch(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos,
+                                                                       ptr(self.K[li]), ptr(self.V[li]), ptr(self.ws), H, Hkv, hd, self.max_len,
+                                                                       self.NSPLIT, hd**-0.5, ptr(wo), wo.numel() * 2, 16 * wo.shape[1] * 2, st),
+                              "merv_decode_attention_split_prefetch")
+                    else:
+                        check(lib.merv_decode_attention_split(ptr(self.q), ptr(self.k), ptr(self.v), ptr(self.cos), ptr(self.sin), pos, ptr(self.K[li]),
+                                                              ptr(self.V[li]), ptr(self.ws), H, Hkv, hd, self.max_len, self.NSPLIT, hd**-0.5, st),
+                              "merv_decode_attention_split")
                     check(lib.merv_decode_oproj_merge(ptr(a.o_proj.weight), x, x, ptr(self.ws), 0, D, H, hd, self.NSPLIT, st),
                           "merv_decode_oproj_merge")
                 else:

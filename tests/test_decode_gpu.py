@@ -700,3 +700,25 @@ def test_gemv_forms_give_the_same_bits_across_processes(dev):
         assert len(lines) == 15, r.stdout
         outs.append(lines)
     assert outs[0] == outs[1] == outs[2] == outs[3]
+
+
+def test_split_attention_with_weight_prefetch_blocks_gives_the_same_partials(dev):
+    """merv_decode_attention_split_prefetch: the extra workgroups only READ the next launch's weights -- partials, cache rows and everything a generation
+    returns are those of merv_decode_attention_split (opt-in path of HipDecoder: prefetch_oproj)."""
+    from merv_amd.llm import HipDecoder, LlamaBackbone
+    llm = LlamaBackbone(dict(vocab_size=320, hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                             num_key_value_heads=4, max_position_embeddings=2048, bos_token_id=1, eos_token_id=None, pad_token_id=0), device=dev)
+    emb = (torch.randn(1, 37, 512, generator=torch.Generator().manual_seed(3)) * 0.5).to(torch.bfloat16).to(dev)
+    was = HipDecoder.prefetch_oproj
+    try:
+        HipDecoder.prefetch_oproj = False
+        ref = llm.generate_from_embeds(emb, max_new_tokens=24)
+        llm._decoders.clear()
+        HipDecoder.prefetch_oproj = True
+        out = llm.generate_from_embeds(emb, max_new_tokens=24)
+        dec = next(iter(llm._decoders.values()))
+        assert isinstance(dec, HipDecoder) and dec.prefetch_oproj and (dec.H * dec.NSPLIT) % 8 == 0
+    finally:
+        HipDecoder.prefetch_oproj = was
+        llm._decoders.clear()
+    assert torch.equal(out, ref)
