@@ -198,7 +198,7 @@ class LlamaBackbone:
                     ids = ids[:, : int(hit[0]) + 1]
             return ids
         if (isinstance(dec, HipDecoder) and do_sample and top_k == 0 and top_p >= 1.0 and repetition_penalty == 1.0 and max_new_tokens > 0
-                and dec.use_greedy_graph):
+                and dec.use_greedy_graph and hasattr(dec.lib, "merv_decode_sample_advance")):  # (an A/B library of an earlier round lacks the entry)
             # temperature sampling entirely on the device (HipDecoder.sample_run): the first token from the prompt's logits here, with the
             # caller's generator (which also seeds the device stream: one draw per generation, so a seeded generator reproduces the text)
             lg = logits / max(temperature, 1e-6)
