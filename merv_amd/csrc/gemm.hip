@@ -382,9 +382,9 @@ MERV_DEVICE void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[WTN / 16][WTM_FUL
                 if (valid[it]) {
                     *(u32x2*)(p.mx_out_q + (size_t)m * p.N + col) = q8;
                     if ((ec & 3) == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)sb;
+                    if (store_c) MERV_PROBE_STORE16(t, (u32x4*)(p.C + (size_t)c_off[it]));  // (uniform) bf16 C beside its MXFP8 copy
                 }
-            }
-            if (store_c && valid[it] && MERV_PROBE_STORE_COND(p)) {  // (uniform)
+            } else if (valid[it] && MERV_PROBE_STORE_COND(p)) {
                 // streaming store: the output (hundreds of MB per launch) is not re-read by this kernel, and written without
                 // L2 allocation the round's write burst drains ~2 us sooner per tile (7.5 vs 9.4 us fixed cost, +1.2 % end to end)
                 MERV_PROBE_STORE16(t, (u32x4*)(p.C + (size_t)c_off[it]));
@@ -555,8 +555,11 @@ MERV_DEVICE void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[4][WTM_FUL
                         if (fq == 0) p.mx_out_scales[mx_scale_offset(m, col >> 5, p.mx_out_groups)] = (uint8_t)(ex + 127);
                     }
                 }
-            }
-            if (store_c && valid[j] && MERV_PROBE_STORE_COND(p)) {  // (uniform)
+                if (store_c && valid[j]) {  // (uniform) bf16 C beside its MXFP8 copy
+                    MERV_PROBE_STORE16(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
+                    MERV_PROBE_STORE16(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
+                }
+            } else if (valid[j] && MERV_PROBE_STORE_COND(p)) {
                 // streaming stores (no L2 allocation: see gemm_epilogue)
                 MERV_PROBE_STORE16(t[0], (u32x4*)(p.C + (size_t)c_off[j]));
                 MERV_PROBE_STORE16(t[1], (u32x4*)(p.C + (size_t)c_off[j] + 32));
@@ -1401,11 +1404,13 @@ int choose_variant(const GemmArgs& a) {
     return a.M > 1024 ? 4 : 1;
 }
 
-// Round 6, re-swept on the round's kernels (tools/sessions/gpu_r6_s3.sh, ms per step at one video, two passes): 32: 9.97 / 9.97 -- 40: 9.79 / 9.81 -- 72: 9.71 / 9.60 --
-// 96: 9.57 / 9.63; two and four videos unchanged (their narrow launches have >= 128 tiles). A sub-round launch lasts as long as ONE block's K-loop, which
-// is MFMA-bound on its CU (0.93 us per K-tile with the chip part empty): the 68-tile launches of LanguageBind / DINOv2 (proj, fc2: 24 / 66 us alone) finish
-// in 17 / 45 us as 136 staggered 256 x 128 blocks, the 39-tile ones of ViViT / SigLIP (20 / 52 us) in 12 / 29 us as 150 blocks of 128 x 128.
-constexpr long SUBROUND_MIN_TILES = 96;
+// Round 6, re-swept on the round's kernels (tools/sessions/gpu_r6_s3.sh, ms per step, two passes): one video 32: 9.97 / 9.97 -- 40: 9.79 / 9.81 -- 72: 9.71 / 9.60 --
+// 96: 9.57 / 9.63; two videos 32: 15.90 / 15.82 -- 72: 15.97 / 15.87 -- 96: 15.99 / 16.02 (and 16.24 -> 16.42 against the round-5 library on another box:
+// ViViT's / SigLIP's 72-tile launches at two videos want the eight-phase kernel); four videos unchanged. A sub-round launch lasts as long as ONE block's K-loop,
+// which is MFMA-bound on its CU (0.93 us per K-tile with the chip part empty): the 68-tile launches of LanguageBind / DINOv2 at one video (proj, fc2: 24 / 66 us
+// alone) finish in 17 / 45 us as 136 staggered 256 x 128 blocks, the 39-tile ones of ViViT / SigLIP (20 / 52 us) in 12 / 29 us as 150 blocks of 128 x 128.
+// 72 = the smallest threshold that takes both.
+constexpr long SUBROUND_MIN_TILES = 72;
 // rows (a multiple of 256 -- or all M rows -- possibly 0) the eight-phase kernel should take from the top of the problem
 int plan_split(const GemmArgs& a) {
     if (g_gemm_variant != 0) return 0;
