@@ -215,8 +215,10 @@ MERV_DEVICE u32x2 mx_quantize8(const float* v, int& scale_byte) {
     float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-    amax = fmaxf(amax, __shfl_xor(amax, 1));
-    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    // maximum over the quad by two DPP moves (quad_perm [1,0,3,2], [2,3,0,1]): no LDS crossbar (__shfl_xor lowers to ds_bpermute, ~100 cycles
+    // each, two per 8 elements in every MXFP8 epilogue); a maximum is exact, the bits do not change (round 6)
+    amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0xB1, 0xf, 0xf, true)));
+    amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0x4E, 0xf, 0xf, true)));
     const int e = mx_shared_exponent(amax);
     const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
     scale_byte = e + 127;
