@@ -518,16 +518,17 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsFinalizeArgs p
         v[i] = t < p.nparts ? pr[(size_t)t * p.M] : float2{0.f, 0.f};
         tot += v[i].x;
     }
-    tot += __shfl_xor(tot, 1, 64);
-    tot += __shfl_xor(tot, 2, 64);
+    // (quad sums by DPP moves -- quad_perm [1,0,3,2], [2,3,0,1] -- instead of ds_bpermute: the same additions in the same order)
+    tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), 0xB1, 0xf, 0xf, true));
+    tot += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, tot), 0x4E, 0xf, 0xf, true));
     const float D = 64.f * (float)p.nparts;
     const float mean = tot / D;
     float m2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i)
         if (sub + 4 * i < p.nparts) { const float d = v[i].x * (1.f / 64.f) - mean; m2 += v[i].y + 64.f * d * d; }
-    m2 += __shfl_xor(m2, 1, 64);
-    m2 += __shfl_xor(m2, 2, 64);
+    m2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m2), 0xB1, 0xf, 0xf, true));
+    m2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m2), 0x4E, 0xf, 0xf, true));
     if (ok && sub == 0) {
         const float rstd = rsqrtf(m2 / D + p.eps);
         *(float2*)(p.stats + 2 * (size_t)row) = float2{rstd, -mean * rstd};
