@@ -153,3 +153,25 @@ def test_batch8_last_video_vs_oracle(dev, name):
     err, cos = rel_l2(out[7:8], ref), _min_cos(out[7:8], ref)
     print(f"{name} B=8 last video: rel_l2={err:.4e} min_cos={cos:.6f}")
     assert err < 2e-2 and cos > 0.999, (name, err, cos)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_every_video_gives_the_same_bits_at_every_small_batch_size(dev, idx):
+    """The GEMM launch plan changes with the batch (round 6: sub-round launches of fewer than 72 tiles take the small tiles, larger ones the
+    eight-phase kernel in its run-time epilogue form, complete rounds the static forms + a remaining-rows launch), the results must not: every
+    tile configuration accumulates K in the same order and every epilogue form rounds alike. Each video of a batch of 1 .. 5 (and 8) gives
+    the bits it gives alone -- three blocks at full width, all four encoders."""
+    from oracle import merv_oracle as O
+    from merv_amd.encoder import HipEncoder
+    cfg = O.merv_full_cfgs()[idx]
+    cfg.layers = 3
+    W = O.random_encoder_weights(cfg, seed=40 + idx)
+    spec = _spec_from_cfg(cfg)
+    enc = HipEncoder(spec, W, dev)
+    pix = torch.randn(spec.pixel_shape(8), generator=torch.Generator().manual_seed(9 + idx)).to(torch.bfloat16).to(dev)
+    alone = [enc.forward(pix[v:v + 1].contiguous()).clone() for v in range(8)]
+    for B in (2, 3, 4, 5, 8):
+        out = enc.forward(pix[:B].contiguous())
+        torch.cuda.synchronize()
+        for v in range(B):
+            assert torch.equal(out[v], alone[v][0]), (cfg.name, B, v)
