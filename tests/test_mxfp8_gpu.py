@@ -232,3 +232,23 @@ def test_mxfp8_mode_stated_tolerance_at_full_depth(dev):
     print(got)
     assert 5e-3 < got[("fc2",)] <= 0.04, got
     assert got[("fc2",)] < got[("qkv", "proj", "fc1", "fc2")] <= 0.10, got
+
+
+@pytest.mark.parametrize("name", ["siglip", "languagebind", "vivit"])
+def test_mxfp8_mode_gives_every_video_the_same_bits_at_every_batch_size(dev, name):
+    """In MXFP8 mode a launch is whole tiles in a static epilogue form + (ragged rows) a second launch of the run-time form of the SAME epilogue
+    mode, and the stream's MXFP8 copy comes from whichever of them wrote the row: a video must give the bits it gives alone whatever the batch
+    -- 1, 2, 3, 5 videos: ragged and whole row counts."""
+    import dataclasses
+    from merv_amd.backbones import random_weights
+    from merv_amd.encoder import HipEncoder, merv_full_specs
+    spec = dataclasses.replace(next(s for s in merv_full_specs() if s.name == name), layers=3)
+    W = random_weights(spec, seed=17)
+    enc = HipEncoder(spec, W, dev).enable_mxfp8()
+    pix = torch.randn(spec.pixel_shape(5), generator=torch.Generator().manual_seed(6)).to(torch.bfloat16).to(dev)
+    alone = [enc.forward(pix[v:v + 1].contiguous()).clone() for v in range(5)]
+    for B in (2, 3, 5):
+        out = enc.forward(pix[:B].contiguous())
+        torch.cuda.synchronize()
+        for v in range(B):
+            assert torch.equal(out[v], alone[v][0]), (name, B, v)
