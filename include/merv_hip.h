@@ -30,8 +30,8 @@ extern "C" {
 /* 2 (round 3): kernel-level profiler classes 5-12 added to merv_prof_*; every round-2 entry point unchanged
  * 3 (round 5): the two opt-in one-launch decode forms (merv_decode_attn_oproj*, merv_decode_chain*: measured slower, EXPERIMENTS.md
  *    section 5) are no longer exported; every other entry point unchanged
- * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms, merv_debug_set_rest_fork, merv_decode_sample_advance and
- *    merv_decode_attention_split_prefetch added; the product build reads no environment variable and
+ * 4 (round 6): merv_tuning_hooks, merv_debug_gemm_mxfp8_forms, merv_debug_set_rest_fork, merv_decode_sample_advance,
+ *    merv_decode_attention_split_prefetch and merv_encoder_set_latency_critical added; the product build reads no environment variable and
  *    merv_debug_set_* are no-ops in it */
 #define MERV_ABI_VERSION 4
 
@@ -231,6 +231,12 @@ int merv_encoder_enable_ln_fold(merv_encoder *enc, void *buf, size_t bytes, void
  */
 size_t merv_encoder_mxfp8_bytes(const merv_encoder *enc);
 int merv_encoder_enable_mxfp8(merv_encoder *enc, void *buf, size_t bytes, void *stream);
+/* Orchestration hint (round 6). When several encoders run concurrently, the chain that ENDS the step (the largest encoder's) should take the
+ * fast, wide form for its sub-round GEMM launches (fewer than 72 tiles of 256 x 256: 136-150 small-tile blocks), while the chains that run beside
+ * it keep the narrow one (39-68 eight-phase blocks from 32 tiles on), which leaves the CUs to it: one video per step 9.43 -> 8.84-8.97 ms. `critical`
+ * != 0 (the default: a lone encoder is its own critical chain) selects the first, 0 the second. Results are bit-identical either way. Mirrors nothing
+ * in the reference (its encoders run one after the other, merv.py:563-566). */
+int merv_encoder_set_latency_critical(merv_encoder *enc, int32_t critical);
 /* Which block GEMMs run on MXFP8 once the mode is enabled: bit 0 qkv (and the temporal qkv), bit 1 attention
  * out-projection (and the temporal one), bit 2 fc1, bit 3 fc2; default 15. The others stay bf16 (accuracy / speed dial). */
 int merv_encoder_set_mxfp8_mask(merv_encoder *enc, int32_t mask);

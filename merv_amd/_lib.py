@@ -98,6 +98,7 @@ SIGNATURES = {
     "merv_encoder_mxfp8_bytes": (_sz, [_vp]),
     "merv_encoder_enable_mxfp8": (C.c_int, [_vp, _vp, _sz, _vp]),
     "merv_encoder_set_mxfp8_mask": (C.c_int, [_vp, _i32]),
+    "merv_encoder_set_latency_critical": (C.c_int, [_vp, _i32]),
     "merv_debug_gemm_mx_out": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "merv_debug_gemm_mxfp8_forms": (C.c_int, [_vp] * 8 + [_i32] * 4 + [_vp] * 4 + [_i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "merv_debug_gemm_stats": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -89,6 +89,7 @@ struct merv_encoder {
     bool mx_folded = false;     // ... on the LayerNorm-folded weights (the fold was enabled first): no LayerNorm / quantisation pass in front of qkv / fc1
     int mx_mask = 15;           // which block GEMMs use it: bit 0 qkv (+ temporal qkv), 1 out-projection (+ temporal), 2 fc1, 3 fc2
     std::vector<MxLayer> mxl;
+    bool latency_critical = true;  // this encoder's chain ends its step (merv_encoder_set_latency_critical): sub-round GEMM launches take the fast wide form
     bool fold = false;          // LayerNorm folded into the qkv / fc1 GEMMs (merv_encoder_enable_ln_fold)
     std::vector<FoldLayer> fl;
     // derived geometry
@@ -200,6 +201,12 @@ Workspace carve(const merv_encoder* e, int nseq, char* base) {
     return w;
 }
 }  // namespace
+
+extern "C" int merv_encoder_set_latency_critical(merv_encoder* e, int32_t critical) {
+    MERV_CHECK(e, "merv_encoder_set_latency_critical: null encoder");
+    e->latency_critical = critical != 0;
+    return 0;
+}
 
 extern "C" int merv_encoder_set_mxfp8_mask(merv_encoder* e, int32_t mask) {
     MERV_CHECK(e, "merv_encoder_set_mxfp8_mask: null encoder");
@@ -372,6 +379,12 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
     const int D = d.dim, nseq = batch * seq_per_video, ntok = e->ntok, M = nseq * ntok;
     const float scale = ATTN_SCALE;
 
+    // every bf16 GEMM of this forward carries the encoder's sub-round policy (GemmArgs::subround_min_tiles): the chain that ends a concurrent step
+    // takes the fast wide form for its narrow launches, the others the form that leaves it the CUs (gemm.hip, SUBROUND_MIN_TILES_BESIDE)
+    auto gemm = [&](GemmArgs g) -> hipError_t {
+        g.subround_min_tiles = e->latency_critical ? 0 : 32;
+        return launch_gemm(g, s);
+    };
     // ---- patch / tubelet embedding: im2col + GEMM (+bias +pos), rows scattered past the prefix tokens ----
     {
         Im2colArgs ic;
@@ -384,7 +397,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
         GemmArgs g = gemm_args(ws.h, d.k_pad, e->w.patch_w, d.k_pad, ws.x, D, nseq * e->P, D, e->w.patch_b, ACT_NONE);
         g.res = (const bf16_t*)e->w.pos; g.ldres = D; g.res_row_mod = e->P;
         g.out_group = e->P; g.out_stride = ntok; g.out_off = d.prefix_tokens;
-        MERV_HIP(launch_gemm(g, s));
+        MERV_HIP(gemm(g));
         if (d.prefix_tokens > 0) {
             PrefixArgs pa{(const bf16_t*)e->w.prefix, ws.x, nseq, ntok, d.prefix_tokens, D};
             MERV_HIP(launch_prefix(pa, s));
@@ -484,7 +497,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
                 else if (mxf) MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_raw_q, e->mxl[li].tqkv_raw_s));  // (tqkv_q holds the folded weight)
                 else MERV_HIP(mx_gemm(q, ws.aq, ws.asc, e->mxl[li].tqkv_q, e->mxl[li].tqkv_s));
             } else {
-                MERV_HIP(launch_gemm(q, s));
+                MERV_HIP(gemm(q));
             }
             TemporalAttnArgs ta{ws.qkv, ws.y, nseq / d.temporal_frames, d.temporal_frames, ntok, d.heads, D, scale};
             if (mx_proj) { ta.mx_q = ws.aq; ta.mx_scales = ws.asc; ta.mx_groups = mx_groups; }
@@ -493,7 +506,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             o.res = ws.x; o.ldres = D;
             produce_x(o, fold_qkv, mx_qkv);  // LN1 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].tproj_q, e->mxl[li].tproj_s));
-            else MERV_HIP(launch_gemm(o, s));
+            else MERV_HIP(gemm(o));
         }
         {
             const bool folded = folded_qkv;  // no LayerNorm pass; the normalisation is algebra in the GEMM epilogue
@@ -506,7 +519,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
                 MERV_HIP(launch_layernorm(ln, s));
             }
             if (mx_qkv) MERV_HIP(mx_gemm(q, folded ? ws.xq : ws.aq, folded ? ws.xsc : ws.asc, e->mxl[li].qkv_q, e->mxl[li].qkv_s));
-            else MERV_HIP(launch_gemm(q, s));
+            else MERV_HIP(gemm(q));
             AttnArgs at{ws.qkv, ws.y, nseq, ntok, d.heads, D, scale};
             at.q_prescaled = folded;  // the folded qkv weight carries scale * log2(e) in its q rows
             if (mx_proj) { at.mx_q = ws.aq; at.mx_scales = ws.asc; at.mx_groups = mx_groups; }
@@ -515,7 +528,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             o.res = ws.x; o.ldres = D; o.lscale = d.layerscale ? L.ls1 : nullptr;
             produce_x(o, fold_fc1, mx_fc1);  // LN2 reads this x next
             if (mx_proj) MERV_HIP(mx_gemm(o, ws.aq, ws.asc, e->mxl[li].proj_q, e->mxl[li].proj_s));
-            else MERV_HIP(launch_gemm(o, s));
+            else MERV_HIP(gemm(o));
         }
         {
             const bool folded = folded_fc1;
@@ -529,7 +542,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
             }
             if (mx_fc2) { f1.mx_out_q = ws.hq; f1.mx_out_scales = ws.hsc; f1.mx_out_groups = mx_groups; }  // fc2's input, whichever kernel runs fc1
             if (mx_fc1) MERV_HIP(mx_gemm(f1, folded ? ws.xq : ws.aq, folded ? ws.xsc : ws.asc, e->mxl[li].fc1_q, e->mxl[li].fc1_s));
-            else MERV_HIP(launch_gemm(f1, s));
+            else MERV_HIP(gemm(f1));
             GemmArgs f2 = gemm_args(ws.h, d.mlp_dim, L.fc2_w, d.mlp_dim, ws.x, D, M, D, L.fc2_b, ACT_NONE);
             f2.res = ws.x; f2.ldres = D; f2.lscale = d.layerscale ? L.ls2 : nullptr;
             // the next reader of x is the following block's LN1 -- unless that block starts with the temporal sub-block
@@ -540,7 +553,7 @@ extern "C" int merv_encoder_forward_select(const merv_encoder* e, const void* pi
                 f2.row_add = e->layers[li + 1].t_emb; f2.row_add_div = ntok; f2.row_add_mod = d.temporal_frames;
             }
             if (mx_fc2) MERV_HIP(mx_gemm(f2, ws.hq, ws.hsc, e->mxl[li].fc2_q, e->mxl[li].fc2_s));
-            else MERV_HIP(launch_gemm(f2, s));
+            else MERV_HIP(gemm(f2));
         }
     }
 

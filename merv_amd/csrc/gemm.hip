@@ -1411,6 +1411,11 @@ int choose_variant(const GemmArgs& a) {
 // alone) finish in 17 / 45 us as 136 staggered 256 x 128 blocks, the 39-tile ones of ViViT / SigLIP (20 / 52 us) in 12 / 29 us as 150 blocks of 128 x 128.
 // 72 = the smallest threshold that takes both.
 constexpr long SUBROUND_MIN_TILES = 72;
+// ... for the chain that ENDS the step. The other chains of a concurrent step keep the eight-phase kernel from 32 tiles on (round 5's value): their 39 / 68
+// blocks then leave the CUs to the critical chain's wide launches -- one video, tools/sessions/gpu_r6_s17.sh, three alternating passes: 72 for every encoder
+// 9.43-9.45 ms, for LanguageBind alone 8.84-8.97, for LanguageBind + DINOv2 9.15-9.25, for the three smaller ones alone 9.91-10.07, for none (round 5) 9.8-9.9.
+// merv_encoder_set_latency_critical() carries the choice; a lone encoder is its own critical chain.
+constexpr long SUBROUND_MIN_TILES_BESIDE = 32;
 // rows (a multiple of 256 -- or all M rows -- possibly 0) the eight-phase kernel should take from the top of the problem
 int plan_split(const GemmArgs& a) {
     if (g_gemm_variant != 0) return 0;
@@ -1423,7 +1428,16 @@ int plan_split(const GemmArgs& a) {
     // itself: see SUBROUND_MIN_TILES)
     if (rounds < 1) {
         static const long min_tiles = merv_tuning_env("MERV_SUBROUND_MIN_TILES") ? atol(merv_tuning_env("MERV_SUBROUND_MIN_TILES")) : SUBROUND_MIN_TILES;  // tuning hook
-        return (full_m * tilesN >= min_tiles) ? a.M : 0;
+        // (experiment hook: MERV_SUBROUND_ONLY_M = "4112,4176": only launches of these row counts take `min_tiles`, every other one round 5's 32 -- i.e. the
+        // chain that ends the step gets the fast wide form, the others keep the form that leaves it the CUs)
+        static const char* only_m = merv_tuning_env("MERV_SUBROUND_ONLY_M");
+        long mt = merv_tuning_env("MERV_SUBROUND_MIN_TILES") ? min_tiles : (a.subround_min_tiles > 0 ? a.subround_min_tiles : min_tiles);
+        if (only_m) {
+            bool hit = false;
+            for (const char* q = only_m; *q;) { if (atol(q) == a.M) hit = true; while (*q && *q != ',') ++q; if (*q) ++q; }
+            mt = hit ? min_tiles : SUBROUND_MIN_TILES_BESIDE;
+        }
+        return (full_m * tilesN >= mt) ? a.M : 0;
     }
     long k = rounds * num_cus() / tilesN;
     if (k > full_m) k = full_m;

@@ -50,6 +50,8 @@ struct GemmArgs {
     uint8_t* mx_out_scales;
     int mx_out_groups;
     int mx_out_keep_c;        // with mx_out_q: 1 = bf16 C is written AS WELL (the residual stream and its MXFP8 copy for the next, LayerNorm-folded MX GEMM)
+    int subround_min_tiles;   // launch_gemm: a launch of less than one round of 256 x 256 tiles takes the eight-phase kernel from this many tiles on
+                              // (0 = the default, SUBROUND_MIN_TILES); set per encoder by the orchestration (merv_encoder_set_latency_critical)
     int no_static_form;       // test hook (merv_debug_gemm_mxfp8_forms): 1 = launch_gemm_mx keeps the run-time epilogue form whatever the shape
     int mx_group0_a;          // MXFP8 launches: 64-row group of mx_scale_a this launch's row 0 belongs to (launch_gemm_mx's second launch starts at rows1)
 };

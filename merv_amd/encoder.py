@@ -191,6 +191,14 @@ class HipEncoder:
         self.ln_fold = True
         return self
 
+    def set_latency_critical(self, critical: bool) -> "HipEncoder":
+        """Orchestration hint (merv_encoder_set_latency_critical): True (the default) = this encoder's chain ends its step and takes the fast wide
+        form for its sub-round GEMM launches; False = it runs beside a longer chain and keeps the form that leaves that chain the CUs. Same bits."""
+        if hasattr(self._lib, "merv_encoder_set_latency_critical"):  # (an A/B library of an earlier round lacks the entry: its one form stays)
+            check(self._lib.merv_encoder_set_latency_critical(self._handle, 1 if critical else 0), "merv_encoder_set_latency_critical")
+        self.latency_critical = bool(critical)
+        return self
+
     MX_GEMMS = {"qkv": 1, "proj": 2, "fc1": 4, "fc2": 8}
 
     def enable_mxfp8(self, gemms=("qkv", "proj", "fc1", "fc2")) -> "HipEncoder":

@@ -84,6 +84,12 @@ class MervVisualPath:
         # cost rank of every encoder (0 = most FLOPs per video): the stream map below is written in ranks
         order = sorted(range(len(self.specs)), key=lambda i: -self.specs[i].flops_per_video())
         self._rank = {i: r for r, i in enumerate(order)}
+        # the chain that ends a concurrent step -- the largest encoder's -- takes the fast wide form for its sub-round GEMM launches, the others keep
+        # the narrow one that leaves it the CUs (round 6: one video 9.43 -> 8.9 ms; launches of a full round or more -- >= 4 videos -- do not depend on it)
+        if concurrent_streams and len(self.encoders) > 1:
+            for i, enc in enumerate(self.encoders):
+                if hasattr(enc, "set_latency_critical"):
+                    enc.set_latency_critical(self._rank[i] == 0)
         self._stream_map_env = _lib.tuning("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
         self.threaded_enqueue: Optional[bool] = None  # see _threaded_enqueue
         self._executor = None
