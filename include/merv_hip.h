@@ -233,8 +233,9 @@ size_t merv_encoder_mxfp8_bytes(const merv_encoder *enc);
 int merv_encoder_enable_mxfp8(merv_encoder *enc, void *buf, size_t bytes, void *stream);
 /* Orchestration hint (round 6). When several encoders run concurrently, the chain that ENDS the step (the largest encoder's) should take the
  * fast, wide form for its sub-round GEMM launches (fewer than 72 tiles of 256 x 256: 136-150 small-tile blocks), while the chains that run beside
- * it keep the narrow one (39-68 eight-phase blocks from 32 tiles on), which leaves the CUs to it: one video per step 9.43 -> 8.84-8.97 ms. `critical`
- * != 0 (the default: a lone encoder is its own critical chain) selects the first, 0 the second. Results are bit-identical either way. Mirrors nothing
+ * it keep the narrow one (39-68 eight-phase blocks from 32 tiles on) and cut their wide launches of up to a round (qkv, fc1) into consecutive
+ * launches of at most 160 tiles, which leaves CUs to it: one video per step 9.43 -> 8.8-9.05 ms. `critical` != 0 (the default: a lone encoder is
+ * its own critical chain) selects the first, 0 the second. Results are bit-identical either way (rows are independent). Mirrors nothing
  * in the reference (its encoders run one after the other, merv.py:563-566). */
 int merv_encoder_set_latency_critical(merv_encoder *enc, int32_t critical);
 /* Which block GEMMs run on MXFP8 once the mode is enabled: bit 0 qkv (and the temporal qkv), bit 1 attention

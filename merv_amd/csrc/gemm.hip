@@ -1416,6 +1416,7 @@ constexpr long SUBROUND_MIN_TILES = 72;
 // 9.43-9.45 ms, for LanguageBind alone 8.84-8.97, for LanguageBind + DINOv2 9.15-9.25, for the three smaller ones alone 9.91-10.07, for none (round 5) 9.8-9.9.
 // merv_encoder_set_latency_critical() carries the choice; a lone encoder is its own critical chain.
 constexpr long SUBROUND_MIN_TILES_BESIDE = 32;
+constexpr long BESIDE_MAX_TILES = 160, BESIDE_WIDE_N = 8;  // width cap of such a chain's wide launches (launch_gemm)
 // rows (a multiple of 256 -- or all M rows -- possibly 0) the eight-phase kernel should take from the top of the problem
 int plan_split(const GemmArgs& a) {
     if (g_gemm_variant != 0) return 0;
@@ -1494,10 +1495,52 @@ void set_gemm_variant(int v) {  // (product build: a no-op -- see merv_tuning_en
     if constexpr (MERV_HOOKS) { g_gemm_variant = v & 0xff; g_gemm_group_m = (v >> 8) & 0xff; }
 }
 
+// rows [r0, r0 + rows) of a problem as a problem of its own (r0 a multiple of 256; plain row-major launches: no row remapping)
+static GemmArgs slice_rows(const GemmArgs& a, int r0, int rows) {
+    GemmArgs g = a;
+    g.M = rows;
+    g.A = a.A + (size_t)r0 * a.lda;
+    g.C = a.C + (size_t)r0 * a.ldc;
+    if (a.res) g.res = a.res + (size_t)r0 * a.ldres;
+    if (a.row_stats) g.row_stats = a.row_stats + 2 * (size_t)r0;
+    g.row_add_row0 = a.row_add_row0 + r0;
+    if (a.stats_out) g.stats_out = a.stats_out + 2 * (size_t)r0;  // same stats_ld: the rows below
+    if (a.mx_out_q) {  // whole 64-row scale groups; the K-tile stride (mx_out_groups) is unchanged
+        g.mx_out_q = a.mx_out_q + (size_t)r0 * a.N;
+        g.mx_out_scales = a.mx_out_scales + (size_t)(r0 / 64) * 256;
+    }
+    return g;
+}
+
 // Host launcher. Requirements (checked): K % 64 == 0, N % 128 == 0, lda/ldw/ldc % 8 == 0.
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M <= 0) return hipSuccess;
+    // A chain that runs BESIDE the one that ends the step (GemmArgs::subround_min_tiles > 0: merv_encoder_set_latency_critical(0)) gives up some of the
+    // chip's WIDTH as well: its wide launches (>= 8 column tiles: qkv, fc1) of more than 160 tiles but no more than a round go out as consecutive launches of
+    // at most 160, so that it never holds more than 160 CUs while the critical chain's launches wait (its rows are independent: same bits). One video,
+    // tools/sessions/gpu_r6_s22.sh, three alternating passes: 9.01-9.07 -> 8.83-8.90 ms (cap 128: 8.78-8.96, 112: 8.88-8.99); two to four videos within
+    // 0.4 %. Narrow launches are never split (a 132-tile launch cut at 128 costs two videos 4 %: gpu_r6_s21.sh). Hooks: MERV_BESIDE_MAX_TILES / _WIDE_N.
+    {
+        static const long cap = merv_tuning_env("MERV_BESIDE_MAX_TILES") ? atol(merv_tuning_env("MERV_BESIDE_MAX_TILES")) : BESIDE_MAX_TILES;
+        static const long wide_n = merv_tuning_env("MERV_BESIDE_WIDE_N") ? atol(merv_tuning_env("MERV_BESIDE_WIDE_N")) : BESIDE_WIDE_N;
+        if (cap > 0 && a_in.subround_min_tiles > 0 && a_in.out_group <= 0 && a_in.res_row_mod <= 0 && a_in.N % 256 == 0) {
+            const long tilesN = a_in.N / 256, tiles = (long)((a_in.M + 255) / 256) * tilesN;
+            const long mt = cap / tilesN;
+            if (tiles > cap && tiles <= num_cus() + tilesN && mt >= 1 && tilesN >= wide_n) {
+                GemmArgs whole = a_in;
+                if (whole.stats_out && whole.stats_ld <= 0) whole.stats_ld = whole.M;
+                for (int r0 = 0; r0 < a_in.M; r0 += (int)mt * 256) {
+                    const int rows = a_in.M - r0 < (int)mt * 256 ? a_in.M - r0 : (int)mt * 256;
+                    GemmArgs g = slice_rows(whole, r0, rows);
+                    g.subround_min_tiles = -1;  // (not again; the slice keeps the eight-phase form from 32 tiles on)
+                    if (hipError_t e = launch_gemm(g, s); e != hipSuccess) return e;
+                }
+                return hipSuccess;
+            }
+        }
+    }
     GemmArgs a = a_in;
+    if (a.subround_min_tiles < 0) a.subround_min_tiles = (int)SUBROUND_MIN_TILES_BESIDE;
     if (g_gemm_group_m > 0) a.group_m = g_gemm_group_m;
     if (a.stats_out && a.stats_ld <= 0) a.stats_ld = a.M;  // rows of the partials array: [N / 64][stats_ld][2]
     if (a.K % BK != 0 || a.N % 128 != 0 || a.K <= 0) return hipErrorInvalidValue;
