@@ -222,13 +222,16 @@ class MervVisualPath:
         return by_rank[:1] + by_rank[:0:-1]
 
     def _threaded_enqueue(self, smap: Sequence[int]) -> bool:
-        """Enqueue the branches from one host thread each? Only when every encoder has a stream of its own (one video per call), never
-        inside a graph capture (a capture belongs to the capturing thread). `threaded_enqueue` (None = that rule) overrides."""
+        """Enqueue the branches from one host thread each? When every encoder has a stream of its own (one video per call: what generate() makes),
+        never inside a graph capture (a capture belongs to the capturing thread). A step is ~700 launches = 2.0 ms of host time on one thread, so
+        the last chain starts 1-2 ms after the first; with the sub-round policy of round 6 the GPU needs 8.7-9.0 ms, and a single call takes
+        9.16-9.23 ms enqueued by one thread, 8.70-8.72 by four (tools/probes/threaded_enqueue_probe.py, same bits; the back-to-back rate, where the
+        host runs ahead anyway, is the same). `threaded_enqueue` (None = that rule, False = never) overrides."""
         if torch.cuda.is_current_stream_capturing():
             return False
         if self.threaded_enqueue is not None:
             return bool(self.threaded_enqueue) and len(set(smap)) == len(smap)
-        return _lib.tuning("MERV_THREADED_ENQUEUE", "0") == "1" and len(set(smap)) == len(smap)
+        return _lib.tuning("MERV_THREADED_ENQUEUE", "1") != "0" and len(set(smap)) == len(smap)
 
     def _pool(self):
         if self._executor is None:
@@ -267,8 +270,10 @@ class MervVisualPath:
                 # a stream per encoder (one video per call): every chain is enqueued by its own host thread (an encoder is ONE library call,
                 # which runs without the GIL), so the chains start together instead of 0.3-1.2 ms apart -- the host needs ~2 ms to enqueue a
                 # step's ~700 launches -- and the largest encoder's chain, which ends the step, is never waiting for the host
+                inference, grad = torch.is_inference_mode_enabled(), torch.is_grad_enabled()  # (thread-local modes: the workers take the caller's)
+
                 def work(i):
-                    with torch.cuda.device(self.device):
+                    with torch.cuda.device(self.device), torch.inference_mode(inference), torch.set_grad_enabled(grad):
                         st = self.streams[smap[i]]
                         st.wait_event(start)
                         outs[i] = branch(i, pixels[i], st)
