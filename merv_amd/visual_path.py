@@ -42,7 +42,14 @@ def _encoder_streams(device: torch.device, n: int) -> List["torch.cuda.Stream"]:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     pool = _ENCODER_STREAMS.setdefault(idx, [])
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device))
+        st = torch.cuda.Stream(device)
+        # HIP binds a stream to its hardware queue at the stream's FIRST USE, not at creation: touch every side stream here, in creation order and from
+        # this one thread, so that the four get one queue each whatever enqueues first later (round 6: with one host thread per chain the first uses
+        # raced, and a process whose streams had landed badly ran its one-video step at 9.8 ms instead of 8.8 for good)
+        with torch.cuda.device(device), torch.cuda.stream(st):
+            torch.zeros(1, device=device)
+        st.synchronize()
+        pool.append(st)
     return pool[:n]
 
 

@@ -14,6 +14,8 @@ import bench
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 specs, bbs, path, extras = bench.build_models(dev)
+if "--threads" in sys.argv:  # MervVisualPath.threaded_enqueue: 1 = one host thread per chain, 0 = one thread (default: the path's own rule)
+    path.threaded_enqueue = sys.argv[sys.argv.index("--threads") + 1] == "1"
 pix = bench.synth_pixels(specs, 1, dev, seed=0)
 
 
