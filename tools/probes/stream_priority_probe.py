@@ -17,6 +17,9 @@ specs, _, path, _ = bench.build_models(dev)
 plain = list(path.streams)
 lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
 hp = torch.cuda.Stream(dev, priority=-1)
+with torch.cuda.stream(hp):  # bind it to its hardware queue now (HIP binds at first use), from this thread
+    torch.zeros(1, device=dev)
+hp.synchronize()
 
 
 def rate(fn, n=30, warm=6):
