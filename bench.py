@@ -653,7 +653,7 @@ def main():
                 roof["power_cap_reference"] = dict(cap, frac_of_it=round(roof["achieved"] / cap["tflops"], 4))
             roof["by_kernel"] = by_kernel
             roof["by_kernel_note"] = (f"one HIP-event bracket per kernel launch, encoders on ONE stream, {args.steps} steps; the classes partition the "
-                                      f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r05_kernel_roofline.json "
+                                      f"step's kernels: sum {tot_ms:.2f} ms per step (event brackets include launch gaps). profiles/r06_kernel_roofline.json "
                                       "joins the same classes to a rocprofv3 --kernel-trace of the same command")
 
     parity = cpu = e2e = None
