@@ -1442,6 +1442,10 @@ int plan_split(const GemmArgs& a) {
     }
     long k = rounds * num_cus() / tilesN;
     if (k > full_m) k = full_m;
+    // (experiment hook, round 6: when what the complete rounds leave over is itself a large part of a round -- two to four videos: a third of a qkv launch --
+    // take it in the eight-phase launch as a last, partial round instead of handing it to the small tiles)
+    static const long rest8 = merv_tuning_env("MERV_REST8_MIN_TILES") ? atol(merv_tuning_env("MERV_REST8_MIN_TILES")) : 0;
+    if (rest8 > 0 && (full_m - k) * tilesN >= rest8) return a.M;
     return (int)(k * 256);
 }
 
