@@ -1527,7 +1527,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     {
         static const long cap = merv_tuning_env("MERV_BESIDE_MAX_TILES") ? atol(merv_tuning_env("MERV_BESIDE_MAX_TILES")) : BESIDE_MAX_TILES;
         static const long wide_n = merv_tuning_env("MERV_BESIDE_WIDE_N") ? atol(merv_tuning_env("MERV_BESIDE_WIDE_N")) : BESIDE_WIDE_N;
-        if (cap > 0 && a_in.subround_min_tiles > 0 && a_in.out_group <= 0 && a_in.res_row_mod <= 0 && a_in.N % 256 == 0) {
+        static const long nocap_m = merv_tuning_env("MERV_BESIDE_NOCAP_M") ? atol(merv_tuning_env("MERV_BESIDE_NOCAP_M")) : -1;  // (experiment: this row count keeps its width)
+        if (cap > 0 && a_in.subround_min_tiles > 0 && a_in.out_group <= 0 && a_in.res_row_mod <= 0 && a_in.N % 256 == 0 && a_in.M != nocap_m) {
             const long tilesN = a_in.N / 256, tiles = (long)((a_in.M + 255) / 256) * tilesN;
             const long mt = cap / tilesN;
             if (tiles > cap && tiles <= num_cus() + tilesN && mt >= 1 && tilesN >= wide_n) {
