@@ -99,7 +99,7 @@ class MervVisualPath:
                     enc.set_latency_critical(self._rank[i] == 0)
         self._stream_map_env = _lib.tuning("MERV_ENCODER_STREAM_MAP")  # probe hook, by rank: "0123" = one stream per encoder, "0111", ...
         self.threaded_enqueue: Optional[bool] = None  # see _threaded_enqueue
-        self._executor = None
+        self._executor, self._executor_pid = None, -1
         self._bufs: Dict[Tuple[int, int, int], Dict[str, torch.Tensor]] = {}
         self._fuse_bufs: Dict[int, Dict[str, torch.Tensor]] = {}
         self._events: Dict[int, Tuple[torch.cuda.Event, List[torch.cuda.Event]]] = {}
@@ -241,9 +241,11 @@ class MervVisualPath:
         return _lib.tuning("MERV_THREADED_ENQUEUE", "1") != "0" and len(set(smap)) == len(smap)
 
     def _pool(self):
-        if self._executor is None:
+        import os
+        if self._executor is None or self._executor_pid != os.getpid():  # (threads do not survive a fork: a child process makes its own pool)
             from concurrent.futures import ThreadPoolExecutor
             self._executor = ThreadPoolExecutor(max_workers=max(1, len(self.encoders) - 1), thread_name_prefix="merv-enqueue")
+            self._executor_pid = os.getpid()
         return self._executor
 
     def _run_branches(self, pixels: Sequence[torch.Tensor], project: bool) -> List[torch.Tensor]:
