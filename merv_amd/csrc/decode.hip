@@ -1010,7 +1010,29 @@ __global__ __launch_bounds__(1024) void sample_advance_kernel(const float* logit
     auto take = [&](float v, int i) {  // ascending i per thread; a NaN logit never wins (torch.multinomial would raise on it)
         if (i != eos && (v > best || idx == 0x7fffffff)) { best = v; idx = i; }
     };
-    for (int q = threadIdx.x; 4 * q < V; q += 1024) {
+    // 16 bytes per lane, eight loads in flight before the first Philox block (as greedy_advance_kernel: one block reads 128 KB of logits -- latency, not
+    // bandwidth; one load per round of the loop made the launch a chain of eight round trips: 18.1 us against 10.8 for the argmax)
+    const int nvec = ((uintptr_t)logits & 15) == 0 ? V >> 2 : 0;
+    for (int b = threadIdx.x; b < nvec; b += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = b + u * 1024;
+            v[u] = q < nvec ? *(const float4*)(logits + 4 * q) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = b + u * 1024;
+            if (q < nvec) {
+                uint32_t c[4] = {(uint32_t)q, (uint32_t)p, (uint32_t)((unsigned long)p >> 32), 0x4D455256u};
+                philox4x32_10(c, k0, k1);
+                const float l[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) take(l[j] == l[j] ? fmaf(l[j], inv_t, gumbel_from_bits(c[j])) : -INFINITY, 4 * q + j);
+            }
+        }
+    }
+    for (int q = nvec + threadIdx.x; 4 * q < V; q += 1024) {  // the tail (and everything, for an unaligned buffer): the same numbers for the same (q, j)
         uint32_t c[4] = {(uint32_t)q, (uint32_t)p, (uint32_t)((unsigned long)p >> 32), 0x4D455256u};
         philox4x32_10(c, k0, k1);
 #pragma unroll
