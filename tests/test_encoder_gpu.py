@@ -209,3 +209,25 @@ def test_one_host_thread_per_chain_gives_the_one_thread_results(dev):
             assert torch.equal(path.forward(pix2)[0], ref2)
     assert torch.equal(path.forward(pix1)[0], ref1)
     assert path._executor is not None
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
+def test_latency_critical_hint_changes_launch_plans_not_bits(dev, idx):
+    """merv_encoder_set_latency_critical: the chain that ends a concurrent step takes the small tiles for its sub-round GEMM launches, a chain beside
+    it the eight-phase form from 32 tiles on and at most 160 tiles per wide launch -- different kernels and launch counts, the same bits (every tile
+    configuration accumulates K in the same order; rows are independent). One, two and three videos."""
+    from oracle import merv_oracle as O
+    from merv_amd.encoder import HipEncoder
+    cfg = O.merv_full_cfgs()[idx]
+    cfg.layers = 3
+    W = O.random_encoder_weights(cfg, seed=80 + idx)
+    spec = _spec_from_cfg(cfg)
+    enc = HipEncoder(spec, W, dev)
+    pix = torch.randn(spec.pixel_shape(3), generator=torch.Generator().manual_seed(19 + idx)).to(torch.bfloat16).to(dev)
+    for B in (1, 2, 3):
+        p = pix[:B].contiguous()
+        a = enc.set_latency_critical(True).forward(p).clone()
+        b = enc.set_latency_critical(False).forward(p).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (cfg.name, B)
+    enc.set_latency_critical(True)
